@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UPSTREAM REFERENCE on CPU.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference is imported read-only from /root/reference with an empty ``cv2`` stub (cv2 is only
+used by its interactive debug blocks).  The fixtures hold DATA ONLY: seeded inputs and the
+reference's outputs / input-gradients for the hot-path functions of SURVEY.md section 8(a):
+
+  warp_*.npz      homo_warping                       (models/mvs4net_utils.py:21-67)
+  stage_*.npz     stagenet.forward, stub regnets     (models/mvs4net_utils.py:1017-1162)
+  range_*.npz     init_range / init_inverse_range / schedule_inverse_range (:69-94)
+  ties.npz        arg-max tie behaviour of the post-regnet half (:1126-1130)
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+sys.path.insert(0, "/root/reference")
+
+from models.mvs4net_utils import (homo_warping, stagenet, init_range, init_inverse_range,  # noqa: E402
+                                  schedule_inverse_range)
+
+torch.set_num_threads(4)
+
+
+def pinhole_views(B, N, H, W, gen, focal=None, baseline=30.0, yaw_deg=1.5, z_shift=4.0):
+    """[B,N,2,4,4] synthetic (extrinsic, intrinsic) pairs: DTU-like pinhole cameras looking down +z."""
+    f = focal if focal is not None else 1.8 * W
+    mats = torch.zeros(B, N, 2, 4, 4)
+    for b in range(B):
+        for v in range(N):
+            K = torch.eye(4)
+            K[0, 0] = f * (1 + 0.01 * v)
+            K[1, 1] = f * (1 - 0.005 * v)
+            K[0, 2] = (W - 1) / 2 + 0.3 * v
+            K[1, 2] = (H - 1) / 2 - 0.2 * v
+            a = math.radians(yaw_deg * v * (1 if b % 2 == 0 else -1))
+            c = math.radians(0.7 * v)
+            Ry = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+            Rx = torch.tensor([[1, 0, 0], [0, math.cos(c), -math.sin(c)], [0, math.sin(c), math.cos(c)]])
+            E = torch.eye(4)
+            E[:3, :3] = Ry @ Rx
+            E[:3, 3] = torch.tensor([baseline * v, -baseline / 3 * v, z_shift * v]) + 0.5 * torch.randn(3, generator=gen)
+            mats[b, v, 0] = E
+            mats[b, v, 1] = K
+    return mats
+
+
+def compose(view):  # same arithmetic the reference does inline before calling homo_warping
+    P = view[:, 0].clone()
+    P[:, :3, :4] = torch.matmul(view[:, 1, :3, :3], view[:, 0, :3, :4])
+    return P
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+# ------------------------------------------------------------------ (i) homo_warping
+def make_warp():
+    g = torch.Generator().manual_seed(101)
+    B, C, D, H, W = 2, 16, 4, 12, 16
+    # (a) normal geometry, some taps out of bounds; src map is a different size than the ref map
+    Hs, Ws = 10, 18
+    mats = pinhole_views(B, 2, H, W, g, baseline=45.0)
+    src = torch.randn(B, C, Hs, Ws, generator=g, requires_grad=True)
+    depth = 400 + 500 * torch.rand(B, D, H, W, generator=g)
+    refP, srcP = compose(mats[:, 0]), compose(mats[:, 1])
+    out = homo_warping(src, srcP, refP, depth)
+    gout = torch.randn(out.shape, generator=g)
+    (out * gout).sum().backward()
+    save("warp_oob", src=src, src_proj=srcP, ref_proj=refP, depth=depth, out=out, gout=gout, gsrc=src.grad)
+    # (b) geometry with z <= 0 for part of the volume (camera behind the plane) and exact z == 0
+    src2 = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    mats2 = pinhole_views(B, 2, H, W, g, baseline=20.0, z_shift=-600.0)
+    depth2 = 300 + 600 * torch.rand(B, D, H, W, generator=g)
+    refP2, srcP2 = compose(mats2[:, 0]), compose(mats2[:, 1])
+    out2 = homo_warping(src2, srcP2, refP2, depth2)
+    gout2 = torch.randn(out2.shape, generator=g)
+    (out2 * gout2).sum().backward()
+    save("warp_negz", src=src2, src_proj=srcP2, ref_proj=refP2, depth=depth2, out=out2, gout=gout2, gsrc=src2.grad)
+    # (c) identity pose: proj == I so the sample lands exactly on the pixel grid; z==0 plane included
+    src3 = torch.randn(1, 4, 6, 7, generator=g)
+    eye = torch.eye(4).unsqueeze(0)
+    depth3 = torch.rand(1, 3, 6, 7, generator=g) + 0.5
+    depth3[0, 1] = 0.0      # rot*[x,y,1]*0 + 0 -> z == 0 -> replaced by 1e-9 (x=y=0 -> 0/1e-9)
+    out3 = homo_warping(src3, eye, eye, depth3)
+    save("warp_identity", src=src3, src_proj=eye, ref_proj=eye, depth=depth3, out=out3)
+
+
+# ------------------------------------------------------------------ (ii)+(iii) stagenet
+class Recorder:
+    """Stub regnet: records the fused volume and reduces it with a fixed per-channel weighting."""
+
+    def __init__(self, chan_weights):
+        self.w = chan_weights
+        self.seen = None
+
+    def __call__(self, vol):
+        self.seen = vol
+        return (vol * self.w.view(1, -1, 1, 1, 1)).sum(1)
+
+
+def make_stage(name, C, G, D, H, W, N, group_cor, attn_fuse_d, training, temp, seed, B=1, split_itv=0.5, plain_sum=False):
+    g = torch.Generator().manual_seed(seed)
+    mats = pinhole_views(B, N, H, W, g)
+    feats = [(0.5 * torch.randn(B, C, H, W, generator=g)).requires_grad_(True) for _ in range(N)]
+    # per-pixel inverse-depth hypotheses around a smooth surface (what the cascade produces)
+    base = 600 + 120 * torch.rand(B, 1, H, W, generator=g)
+    inv = 1.0 / base + (torch.arange(D).view(1, D, 1, 1) - (D - 1) / 2) * 6e-5
+    hypo = 1.0 / inv
+    nchan = G if group_cor else C
+    # x12 so the stub logits spread enough for a peaked (non-uniform) softmax over depth
+    cw = torch.ones(nchan) if plain_sum else 12.0 * (0.5 + torch.rand(nchan, generator=g))
+    reg = Recorder(cw)
+    net = stagenet(inverse_depth=True, mono=True, attn_fuse_d=attn_fuse_d, vis_ETA=False, attn_temp=temp)
+    net.train(training)
+    out = net(feats, mats, hypo, reg, 0, group_cor=group_cor, group_cor_dim=G, split_itv=split_itv)
+    lw = torch.randn(out["attn_weight"].shape, generator=g)
+    (out["attn_weight"] * lw).sum().backward()
+    arrays = dict(proj=mats, hypo=hypo, chan_w=cw, loss_w=lw, cor_feats=reg.seen,
+                  attn_weight=out["attn_weight"], depth=out["depth"],
+                  conf=out["photometric_confidence"], inv_min=out["inverse_min_depth"],
+                  inv_max=out["inverse_max_depth"],
+                  meta=np.array([C, G, D, H, W, N, int(group_cor), int(attn_fuse_d), int(training), B]),
+                  temp=np.float32(temp), split_itv=np.float32(split_itv))
+    for i, f in enumerate(feats):
+        arrays["feat%d" % i] = f
+        arrays["gfeat%d" % i] = f.grad
+    save(name, **arrays)
+
+
+def make_stages():
+    # the four DTU stage shapes (C,G,D) at tiny resolution, group correlation, train + eval
+    make_stage("stage_c64g8d8_train", 64, 8, 8, 8, 10, 3, True, True, True, 2.0, 201)
+    make_stage("stage_c32g8d8_eval", 32, 8, 8, 10, 12, 3, True, True, False, 2.0, 202)
+    make_stage("stage_c16g4d4_train", 16, 4, 4, 12, 16, 4, True, True, True, 2.0, 203, B=2)
+    make_stage("stage_c8g4d4_eval", 8, 4, 4, 14, 16, 5, True, True, False, 2.0, 204, split_itv=1.0)
+    make_stage("stage_c8g4d4_train", 8, 4, 4, 14, 16, 5, True, True, True, 2.0, 214, split_itv=1.0, plain_sum=True)
+    # hi-res config's first stage: D = 16
+    make_stage("stage_c64g8d16_train", 64, 8, 16, 6, 8, 3, True, True, True, 2.0, 205)
+    # no group correlation (squared difference volume, C channels out)
+    make_stage("stage_c16nogroup_train", 16, 16, 4, 10, 12, 3, False, True, True, 1.0, 206)
+    make_stage("stage_c8nogroup_eval", 8, 8, 8, 10, 12, 3, False, True, False, 2.0, 207)
+    # attn_fuse_d = False (per-pixel view weight)
+    make_stage("stage_c16g4d4_nofuse_train", 16, 4, 4, 10, 12, 3, True, False, True, 2.0, 208)
+    make_stage("stage_c8nogroup_nofuse_eval", 8, 8, 4, 10, 12, 3, False, False, False, 2.0, 209)
+
+
+# ------------------------------------------------------------------ (iv) ranges
+def make_ranges():
+    g = torch.Generator().manual_seed(301)
+    dv = torch.tensor([[425.0, 935.0], [300.0, 1200.0]])
+    for D in (4, 8, 16):
+        save("range_init_d%d" % D, depth_values=dv,
+             inverse=init_inverse_range(dv, D, dv.device, dv.dtype, 5, 6),
+             linear=init_range(dv, D, dv.device, dv.dtype, 5, 6))
+    dv192 = torch.linspace(425.0, 935.0, 192).unsqueeze(0)
+    save("range_init_192", depth_values=dv192, inverse=init_inverse_range(dv192, 8, dv192.device, dv192.dtype, 3, 4),
+         linear=init_range(dv192, 8, dv192.device, dv192.dtype, 3, 4))
+    for (D, Hp, Wp) in ((8, 9, 11), (4, 16, 20), (16, 5, 7)):
+        base = 1.0 / (500 + 300 * torch.rand(2, Hp, Wp, generator=g))
+        half = 2e-5 + 1e-4 * torch.rand(2, Hp, Wp, generator=g)
+        imin, imax = base + half, base - half
+        save("range_sched_d%d" % D, inv_min=imin, inv_max=imax,
+             out=schedule_inverse_range(imin, imax, D, 2 * Hp, 2 * Wp))
+
+
+# ------------------------------------------------------------------ (v) ties
+def make_ties():
+    g = torch.Generator().manual_seed(401)
+    B, D, H, W = 1, 8, 4, 8
+    logits = torch.randn(B, D, H, W, generator=g)
+    logits[0, :, 0, 0] = 0.25                      # all equal -> index 0
+    logits[0, :, 0, 1] = -1.0
+    logits[0, 3, 0, 1] = 2.0
+    logits[0, 6, 0, 1] = 2.0                       # two-way tie -> first (3)
+    logits[0, :, 0, 2] = torch.tensor([0.1, 0.7, 0.7, 0.7, -3, 0.2, 0.7, 0.0])
+    logits[0, :, 0, 3] = 50.0 + torch.arange(D) * 1e-30   # ties after rounding
+    logits[0, 7, 0, 4] = 9.0                       # max at the last index
+    logits[0, 0, 0, 5] = 9.0                       # max at the first index
+    logits[0, :, 1, 0] = -40.0                     # large negative common offset
+    logits[0, 2, 1, 0] = -39.5
+    hypo = 1.0 / (1.0 / 900 + torch.arange(D).view(1, D, 1, 1) * 1.5e-4 + 1e-5 * torch.rand(B, 1, H, W, generator=g))
+
+    feats = [torch.zeros(B, 8, H, W), torch.zeros(B, 8, H, W)]
+    mats = pinhole_views(B, 2, H, W, g)
+    for training in (True, False):
+        net = stagenet(inverse_depth=True, mono=False, attn_fuse_d=True, attn_temp=2)
+        net.train(training)
+        out = net(feats, mats, hypo, lambda vol: logits, 0, group_cor=True, group_cor_dim=4, split_itv=0.5)
+        idx = out["attn_weight"].max(1)[1]
+        save("ties_%s" % ("train" if training else "eval"), logits=logits, hypo=hypo,
+             attn_weight=out["attn_weight"], depth=out["depth"], index=idx,
+             conf=out["photometric_confidence"], inv_min=out["inverse_min_depth"], inv_max=out["inverse_max_depth"])
+
+
+if __name__ == "__main__":
+    make_warp()
+    make_stages()
+    make_ranges()
+    make_ties()
