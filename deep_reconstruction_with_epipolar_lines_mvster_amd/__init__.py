@@ -1,0 +1,10 @@
+"""MI355X-native (gfx950) implementation of MVSTER's cost-volume + epipolar-attention hot path.
+
+Drop-in for the hot-path symbols of the reference's ``models/mvs4net_utils.py`` (see hotpath.py);
+the kernels live in csrc/ behind the C ABI of include/mvster_hip.h.
+"""
+from .hotpath import (homo_warping, stagenet, init_range, init_inverse_range, schedule_inverse_range,  # noqa: F401
+                      stage_poses, relative_pose, fused_cost_volume, depth_regress)
+
+__all__ = ["homo_warping", "stagenet", "init_range", "init_inverse_range", "schedule_inverse_range",
+           "stage_poses", "relative_pose", "fused_cost_volume", "depth_regress"]

@@ -1,0 +1,101 @@
+"""ctypes binding of libmvster_hip.so (the C ABI declared in include/mvster_hip.h).
+
+There is NO fallback: if the shared library is missing or does not export the full ABI, loading
+raises, and every operator of the package raises with it.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvster_hip.so")
+ABI_VERSION = 1
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> argtypes, exactly the prototypes of include/mvster_hip.h
+PROTOTYPES = {
+    "mvster_relative_pose": [_vp, _vp, _vp, _i, _vp],
+    "mvster_stage_poses": [_vp, _vp, _i, _i, _vp],
+    "mvster_warp_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvster_warp_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvster_cost_volume_fwd": [_vp, _vpp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "mvster_cost_volume_bwd": [_vp, _vp, _vp, _vp, _vpp, _i, _vp, _vp, _vp, _vpp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "mvster_depth_regress_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "mvster_softmax_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvster_init_range": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvster_schedule_inverse_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+}
+
+MVSTER_OK = 0
+MVSTER_ERR_UNSUPPORTED = 3
+
+_lock = threading.Lock()
+_lib = None
+
+
+class MvsterError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+    def __init__(self, fn, code, text):
+        super().__init__("%s failed: [%d] %s" % (fn, code, text))
+        self.code = code
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmvster_hip.so is not built (%s). Build it with "
+                "`python -m deep_reconstruction_with_epipolar_lines_mvster_amd.build`; "
+                "this package has no CPU or PyTorch fallback." % LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64.so.7; importing torch first makes the dynamic loader
+        # resolve our DT_NEEDED entry to that already-loaded runtime (one HIP runtime per process, so
+        # torch's streams and device pointers are valid in our launches).
+        import torch  # noqa: F401
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        lib.mvster_abi_version.restype = ctypes.c_int
+        lib.mvster_error_string.restype = ctypes.c_char_p
+        lib.mvster_error_string.argtypes = [ctypes.c_int]
+        got = lib.mvster_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError("libmvster_hip.so ABI version %d, binding expects %d" % (got, ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an ABI function; non-zero status -> MvsterError."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != MVSTER_OK:
+        raise MvsterError(name, rc, lib.mvster_error_string(rc).decode())
+
+
+def try_call(name, *args):
+    """Like call() but returns False on MVSTER_ERR_UNSUPPORTED (caller picks another HIP route)."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc == MVSTER_ERR_UNSUPPORTED:
+        return False
+    if rc != MVSTER_OK:
+        raise MvsterError(name, rc, lib.mvster_error_string(rc).decode())
+    return True
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return ctypes.cast(arr, _vpp), arr   # keep `arr` alive for the duration of the call

@@ -1,0 +1,54 @@
+// Shared declarations of the fused cost-volume kernels (cost_volume_fwd.hip / cost_volume_bwd.hip).
+#pragma once
+
+#include <math.h>
+
+#include "mvster_device.h"
+#include "mvster_host.h"
+
+namespace mvster {
+
+struct SrcPtrs {
+    const float* p[MVSTER_MAX_SRC_VIEWS];
+};
+struct GradPtrs {
+    float* p[MVSTER_MAX_SRC_VIEWS];
+};
+
+struct VolumeDims {
+    int H, W, Hs, Ws, S, ntiles;
+    float temp;     // attn_temp
+    float sqrt_c;   // (float)sqrt(C), the reference divides the view weight by math.sqrt(C)
+};
+
+// (channels per group, groups) pairs instantiated: C in {8,16,32,64} x G in {4,8}
+#define MVSTER_FOR_SHAPES(X) \
+    X(2, 4) X(4, 4) X(8, 4) X(16, 4) X(1, 8) X(2, 8) X(4, 8) X(8, 8)
+
+inline bool shape_instantiated(int C, int G, int D) {
+    if (G <= 0 || C % G != 0) return false;
+    const int cpg = C / G;
+    const bool cg = (G == 4 && (cpg == 2 || cpg == 4 || cpg == 8 || cpg == 16)) ||
+                    (G == 8 && (cpg == 1 || cpg == 2 || cpg == 4 || cpg == 8));
+    return cg && (D == 4 || D == 8 || D == 16);
+}
+
+// One lane per pixel (DPL = D) needs enough pixels to give every SIMD of the 256 CUs several waves
+// and few enough channels for the per-lane state to stay in registers; otherwise D lanes per pixel.
+constexpr long long kMinPixelWaves = 8192;
+constexpr int kMaxWideChannels = 16;
+
+inline bool pick_pixel_per_lane(int B, int HW, int C, int D) {
+    return D == 4 && C <= kMaxWideChannels && ((long long)B * HW) / kWave >= kMinPixelWaves;
+}
+
+inline int check_volume(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, float temp) {
+    MVSTER_REQUIRE_SHAPE(B > 0 && C > 0 && G > 0 && D > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && S > 0);
+    MVSTER_REQUIRE_SHAPE(B <= 65535 && C % G == 0 && temp != 0.0f);
+    MVSTER_REQUIRE_SHAPE((long long)H * W <= kMaxPlane && (long long)Hs * Ws <= kMaxPlane);
+    if (S > MVSTER_MAX_SRC_VIEWS) return MVSTER_ERR_UNSUPPORTED;
+    if (!shape_instantiated(C, G, D)) return MVSTER_ERR_UNSUPPORTED;
+    return MVSTER_OK;
+}
+
+}  // namespace mvster

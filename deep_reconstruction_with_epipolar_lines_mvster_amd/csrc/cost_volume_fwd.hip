@@ -1,0 +1,157 @@
+// A2/A3  fused homography warp + group-wise correlation + softmax-over-depth view weight + fusion
+// over source views, forward and backward.   reference: models/mvs4net_utils.py:1036-1102 (+ autograd).
+//
+// Work decomposition (gfx950, wave64): a workgroup of 256 lanes owns 256/DL consecutive reference
+// pixels (row-major), DL = D/DPL lanes per pixel, each lane carrying DPL depth hypotheses.  Lanes of
+// one pixel are adjacent (d fastest), so the softmax / arg reductions over depth are xor-shuffles
+// inside an aligned lane group and the per-view state (G x DPL correlations, running numerator and
+// denominator) lives in registers for the whole source-view loop.  The [B,C,D,H,W] warped volume of
+// the reference is never written: HBM traffic is one read of every feature map, the hypotheses,
+// and one write of the fused [B,G,D,H,W] volume.
+//   DPL = D  (one lane = one pixel): fully coalesced along the row, used when there are enough
+//             pixels to fill 256 CUs (D = 4 stages at full resolution);
+//   DPL = 1  (D lanes per pixel): D x more lanes, used for the small coarse stages.
+// Feature maps are NCHW planes: for a fixed (channel, depth) the 4 bilinear taps of consecutive
+// pixels fall on consecutive addresses of at most two source rows.
+#include "cost_volume_common.h"
+
+namespace mvster {
+
+// --------------------------------------------------------------------------------------------- forward
+template <int CPG, int G, int D, int DPL>
+__global__ void __launch_bounds__(kBlock)
+cost_volume_fwd_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float* __restrict__ pose,
+                       const float* __restrict__ hypo, float* __restrict__ vol, float* __restrict__ wsum,
+                       VolumeDims dm) {
+    constexpr int C = CPG * G;
+    constexpr int DL = D / DPL;
+    constexpr int PXB = kBlock / DL;
+    constexpr bool kRefInRegs = (C <= 16);
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    if (tile >= dm.ntiles) return;
+    const int b = blockIdx.y;
+    const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
+    const int dl = threadIdx.x % DL, pl = threadIdx.x / DL;
+    const int praw = tile * PXB + pl;
+    const bool live = praw < HW;
+    const int p = live ? praw : HW - 1;
+    const int y = p / dm.W, x = p - y * dm.W;
+    const float fx = (float)x, fy = (float)y;
+    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+
+    const float* __restrict__ refp = ref + (size_t)b * C * HW + p;
+    float refv[kRefInRegs ? C : 1];
+    if constexpr (kRefInRegs) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) refv[c] = refp[(size_t)c * HW];
+    }
+    float hyp[DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) hyp[j] = hypo[((size_t)b * D + dl * DPL + j) * HW + p];
+
+    float den[DPL], num[G][DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        den[j] = 1e-8f;                                   // cor_weight_sum starts at 1e-8 (:1037)
+#pragma unroll
+        for (int g = 0; g < G; ++g) num[g][j] = 0.0f;
+    }
+
+    for (int s = 0; s < dm.S; ++s) {
+        const float* __restrict__ srcb = srcs.p[s] + (size_t)b * C * HWs;
+        const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
+        const Ray ray = rotate_pixel(q, fx, fy);
+        float cor[G][DPL];
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            const Taps t = project_taps(q, ray, hyp[j], dm.Hs, dm.Ws, half_w, half_h);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < CPG; ++k) {
+                    const int c = g * CPG + k;
+                    const float r = kRefInRegs ? refv[kRefInRegs ? c : 0] : refp[(size_t)c * HW];
+                    acc = fmaf(sample(srcb + (size_t)c * HWs, t), r, acc);
+                }
+                cor[g][j] = acc * (1.0f / CPG);           // mean over the group's channels (:1069)
+            }
+        }
+        // view weight: softmax over ALL D hypotheses of sum_g cor / temp, then / sqrt(C)  (:1083)
+        float a[DPL], m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            float sg = cor[0][j];
+#pragma unroll
+            for (int g = 1; g < G; ++g) sg += cor[g][j];
+            a[j] = sg / dm.temp;
+            m = fmaxf(m, a[j]);
+        }
+        m = group_max<DL>(m);
+        float e[DPL], sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            e[j] = expf(a[j] - m);
+            sum += e[j];
+        }
+        sum = group_sum<DL>(sum);
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            const float w = (e[j] / sum) / dm.sqrt_c;
+            den[j] += w;                                   // (:1084)
+#pragma unroll
+            for (int g = 0; g < G; ++g) num[g][j] += w * cor[g][j];   // (:1085)
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        const int d = dl * DPL + j;
+#pragma unroll
+        for (int g = 0; g < G; ++g) vol[(((size_t)b * G + g) * D + d) * HW + p] = num[g][j] / den[j];   // (:1100)
+        if (wsum != nullptr) wsum[((size_t)b * D + d) * HW + p] = den[j];
+    }
+}
+
+template <int CPG, int G, int D, int DPL>
+static int launch_fwd(const float* ref, const SrcPtrs& srcs, const float* pose, const float* hypo, float* vol,
+                      float* wsum, int B, VolumeDims dm, hipStream_t st) {
+    constexpr int PXB = kBlock / (D / DPL);
+    dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
+    dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
+    hipLaunchKernelGGL((cost_volume_fwd_kernel<CPG, G, D, DPL>), grid, dim3(kBlock), 0, st, ref, srcs, pose, hypo, vol,
+                       wsum, dm);
+    return launch_status();
+}
+
+}  // namespace mvster
+
+extern "C" int mvster_cost_volume_fwd(const float* ref, const float* const* srcs, int S, const float* pose,
+                                      const float* hypo, float* vol, float* wsum, int B, int C, int G, int D, int H,
+                                      int W, int Hs, int Ws, float attn_temp, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(ref); MVSTER_REQUIRE_PTR(srcs); MVSTER_REQUIRE_PTR(pose); MVSTER_REQUIRE_PTR(hypo);
+    MVSTER_REQUIRE_PTR(vol);
+    if (int rc = check_volume(S, B, C, G, D, H, W, Hs, Ws, attn_temp)) return rc;
+    SrcPtrs sp{};
+    for (int s = 0; s < S; ++s) {
+        MVSTER_REQUIRE_PTR(srcs[s]);
+        sp.p[s] = srcs[s];
+    }
+    VolumeDims dm{H, W, Hs, Ws, S, 0, attn_temp, (float)sqrt((double)C)};
+    const hipStream_t st = as_stream(stream);
+    const int cpg = C / G;
+    const bool wide = pick_pixel_per_lane(B, H * W, C, D);
+#define X(CPG_, G_)                                                                                          \
+    if (cpg == CPG_ && G == G_) {                                                                            \
+        if constexpr (CPG_ * G_ <= kMaxWideChannels) {                                                       \
+            if (D == 4 && wide) return launch_fwd<CPG_, G_, 4, 4>(ref, sp, pose, hypo, vol, wsum, B, dm, st); \
+        }                                                                                                    \
+        if (D == 4) return launch_fwd<CPG_, G_, 4, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, st);            \
+        if (D == 8) return launch_fwd<CPG_, G_, 8, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, st);            \
+        if (D == 16) return launch_fwd<CPG_, G_, 16, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, st);          \
+    }
+    MVSTER_FOR_SHAPES(X)
+#undef X
+    return MVSTER_ERR_UNSUPPORTED;
+}

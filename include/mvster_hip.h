@@ -1,0 +1,145 @@
+/*
+ * mvster_hip.h -- C ABI of libmvster_hip.so, the MI355X (gfx950) implementation of the MVSTER
+ * cost-volume / epipolar-attention hot path.
+ *
+ * The upstream reference has no native layer: the path is a sequence of PyTorch operators inside
+ * models/mvs4net_utils.py.  Each entry point below replaces one such operator sequence; the
+ * citation after "replaces:" is the reference code a maintainer would swap for the call
+ * (see INTEGRATION.md for the Python/ctypes binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated otherwise; tensors are dense,
+ *     row-major in the order written in the comment ([B,C,H,W] == NCHW contiguous);
+ *   - inputs are borrowed and never written; outputs are fully overwritten (no accumulate-into);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream) and the
+ *     call returns without synchronising; nothing is allocated, no global mutable state is kept,
+ *     every function is re-entrant and may be called concurrently from several host threads;
+ *   - the active HIP device must be the one that owns the pointers (the Python host sets it);
+ *   - return value: MVSTER_OK (0) or an MVSTER_ERR_* code; mvster_error_string() explains it.
+ *     Nothing aborts; on error no kernel has been launched.
+ */
+#ifndef MVSTER_HIP_H
+#define MVSTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVSTER_ABI_VERSION 1
+
+#define MVSTER_OK 0
+#define MVSTER_ERR_NULL_POINTER 1   /* a required pointer argument is NULL                     */
+#define MVSTER_ERR_BAD_SHAPE 2      /* a dimension is <= 0, inconsistent, or too large          */
+#define MVSTER_ERR_UNSUPPORTED 3    /* valid request outside what the fused kernels instantiate */
+#define MVSTER_ERR_LAUNCH 4         /* the HIP runtime rejected a launch / memset               */
+
+#define MVSTER_MAX_SRC_VIEWS 16     /* source views per call of the fused kernels               */
+#define MVSTER_MAX_DEPTHS 64        /* depth hypotheses per pixel (generic kernels)             */
+
+typedef void *mvster_stream_t;
+
+int mvster_abi_version(void);
+const char *mvster_error_string(int code);
+
+/* --------------------------------------------------------------------------------------------
+ * Relative pose of a source view w.r.t. the reference view.
+ *   pose[b] = 12 floats: rot (3x3 row-major) then trans (3) of  src_proj[b] @ inverse(ref_proj[b]).
+ * The 4x4 inverse and product are evaluated in fp64 on the device and rounded once to fp32.
+ * replaces: models/mvs4net_utils.py:32-34 (torch.inverse + matmul inside homo_warping).
+ *   src_proj, ref_proj : [B,4,4]        pose : [B,12]
+ */
+int mvster_relative_pose(const float *src_proj, const float *ref_proj, float *pose, int B,
+                         mvster_stream_t stream);
+
+/* Same, starting from the dataset's matrices: proj_matrices [B,N,2,4,4] with [:, v, 0] = extrinsic
+ * and [:, v, 1, :3, :3] = intrinsic; view 0 is the reference.  P_v = E_v with rows 0..2 replaced by
+ * K_v[:3,:3] @ E_v[:3,:4]; pose[b, v-1] = P_v @ inverse(P_0) for v = 1..N-1.
+ * replaces: models/mvs4net_utils.py:1030,1047-1050 + :32-34.
+ *   proj_matrices : [B,N,2,4,4]         pose : [B,N-1,12]
+ */
+int mvster_stage_poses(const float *proj_matrices, float *pose, int B, int N, mvster_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A1  homo_warping: bilinear (zeros padding, align_corners=True) gather of src features at the
+ * projection of every (reference pixel, depth hypothesis).
+ * replaces: models/mvs4net_utils.py:21-67 (4-D src_fea branch).
+ *   src : [B,C,Hs,Ws]   pose : [B,12]   depth : [B,D,Hr,Wr]   out : [B,C,D,Hr,Wr]
+ */
+int mvster_warp_fwd(const float *src, const float *pose, const float *depth, float *out, int B, int C,
+                    int D, int Hr, int Wr, int Hs, int Ws, mvster_stream_t stream);
+
+/* Gradient of mvster_warp_fwd w.r.t. src (the sampling grid carries no gradient, :31).
+ *   gout : [B,C,D,Hr,Wr]   gsrc : [B,C,Hs,Ws] (overwritten; fp32 atomics, summation order varies)
+ */
+int mvster_warp_bwd(const float *gout, const float *pose, const float *depth, float *gsrc, int B, int C,
+                    int D, int Hr, int Wr, int Hs, int Ws, mvster_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A2  fused warp + group-wise correlation + softmax-over-depth view weighting + fusion over the
+ * S source views (group_cor=True, attn_fuse_d=True -- the configuration of every reference script).
+ * Never materialises the [B,C,D,H,W] warped volume.
+ * replaces: models/mvs4net_utils.py:1036-1102 (the src-view loop and the normalisation).
+ *   ref   : [B,C,H,W]            srcs : host array of S device pointers, each [B,C,Hs,Ws]
+ *   pose  : [B,S,12]             hypo : [B,D,H,W]
+ *   vol   : [B,G,D,H,W]  fused correlation volume (regnet input)
+ *   wsum  : [B,D,H,W]    1e-8 + sum_s w_s   (saved for the backward pass; may be NULL)
+ * Supported: C in {8,16,32,64} with G in {4,8}, C % G == 0, D in {4,8,16}; otherwise
+ * MVSTER_ERR_UNSUPPORTED (the host then composes mvster_warp_fwd with device tensor ops).
+ */
+int mvster_cost_volume_fwd(const float *ref, const float *const *srcs, int S, const float *pose,
+                           const float *hypo, float *vol, float *wsum, int B, int C, int G, int D, int H,
+                           int W, int Hs, int Ws, float attn_temp, mvster_stream_t stream);
+
+/* A3  gradient of mvster_cost_volume_fwd w.r.t. every feature map (recompute-based).
+ *   gvol : [B,G,D,H,W]   vol, wsum : the forward outputs
+ *   gref : [B,C,H,W] (overwritten)   gsrcs : host array of S device pointers, each [B,C,Hs,Ws]
+ *   (overwritten; fp32 atomics).
+ */
+int mvster_cost_volume_bwd(const float *gvol, const float *vol, const float *wsum, const float *ref,
+                           const float *const *srcs, int S, const float *pose, const float *hypo,
+                           float *gref, float *const *gsrcs, int B, int C, int G, int D, int H, int W,
+                           int Hs, int Ws, float attn_temp, mvster_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A4  post-regnet half: softmax over depth, FIRST arg-max, depth gather, confidence, next range.
+ * replaces: models/mvs4net_utils.py:1109-1113,1126-1138,1151-1156.
+ *   logits, hypo : [B,D,H,W]
+ *   attn   : [B,D,H,W]  softmax_d(logits)
+ *   depth  : [B,H,W]    hypo gathered at the first arg-max of attn
+ *   index  : [B,H,W]    int32 arg-max index (may be NULL)
+ *   conf   : [B,H,W]    max_d(logits) / sum_d(logits) on the RAW logits (eval mode; NULL in training)
+ *   inv_min, inv_max : [B,H,W]  1/depth +- split_itv * (1/hypo[:,2] - 1/hypo[:,1])
+ *                      (both NULL when inverse_depth is off; needs D >= 3 otherwise)
+ */
+int mvster_depth_regress_fwd(const float *logits, const float *hypo, float *attn, float *depth,
+                             int32_t *index, float *conf, float *inv_min, float *inv_max, int B, int D,
+                             int H, int W, float split_itv, mvster_stream_t stream);
+
+/* Softmax backward: glogits = attn * (gattn - sum_d(gattn * attn)).   all [B,D,H,W] */
+int mvster_softmax_bwd(const float *attn, const float *gattn, float *glogits, int B, int D, int H, int W,
+                       mvster_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A5  first-stage hypotheses from depth_values[:,0] (min) and depth_values[:,K-1] (max).
+ *   inverse != 0 : 1 / (1/dmax + (1/dmin - 1/dmax) * k/(D-1))   (plane 0 = far plane)
+ *   inverse == 0 : dmin + k * (dmax - dmin)/(D-1)
+ * replaces: models/mvs4net_utils.py:79-85 (init_inverse_range) and :69-77 (init_range).
+ *   depth_values : [B,K]   out : [B,D,H,W]
+ */
+int mvster_init_range(const float *depth_values, int K, float *out, int B, int D, int H, int W, int inverse,
+                      mvster_stream_t stream);
+
+/* A6  next-stage hypotheses: linear ramp in inverse depth between inv_max and inv_min at the
+ * previous resolution, x2 bilinear (align_corners=True) upsample, reciprocal.
+ * replaces: models/mvs4net_utils.py:87-94 (schedule_inverse_range).
+ *   inv_min, inv_max : [B,Hp,Wp]   out : [B,D,H,W]
+ */
+int mvster_schedule_inverse_range(const float *inv_min, const float *inv_max, float *out, int B, int D,
+                                  int Hp, int Wp, int H, int W, mvster_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVSTER_HIP_H */
