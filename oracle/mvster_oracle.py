@@ -64,10 +64,13 @@ def sampling_grid(rot, trans, depth_values, Hs, Ws):
     """
     B, D, Hr, Wr = depth_values.shape
     dev = depth_values.device
-    rows = torch.arange(0, Hr, dtype=torch.float32, device=dev)
-    cols = torch.arange(0, Wr, dtype=torch.float32, device=dev)
+    # float32 in the reference (:36-37); the dtype follows the inputs so that the same restatement run
+    # in float64 serves as the exact arbiter when the fp32 paths disagree at rounding level
+    fdt = depth_values.dtype
+    rows = torch.arange(0, Hr, dtype=fdt, device=dev)
+    cols = torch.arange(0, Wr, dtype=fdt, device=dev)
     yy, xx = torch.meshgrid(rows, cols, indexing="ij")
-    homog = torch.stack((xx.reshape(-1), yy.reshape(-1), torch.ones(Hr * Wr, device=dev)))
+    homog = torch.stack((xx.reshape(-1), yy.reshape(-1), torch.ones(Hr * Wr, dtype=fdt, device=dev)))
     homog = homog.unsqueeze(0).expand(B, 3, Hr * Wr)
     rotated = torch.matmul(rot, homog)                                   # [B,3,HW]
     pts = rotated.unsqueeze(2) * depth_values.reshape(B, 1, D, Hr * Wr)   # [B,3,D,HW]
@@ -159,7 +162,7 @@ def regress_depth(logits, depth_hypo, training, inverse_depth=True, split_itv=1.
         with torch.no_grad():
             conf = raw_max / raw_sum
     else:
-        conf = torch.tensor(0.0, dtype=torch.float32, device=logits.device)
+        conf = torch.tensor(0.0, dtype=torch.float32, device=logits.device)   # (:1144)
     out["depth"] = depth
     out["photometric_confidence"] = conf
     out["hypo_depth"] = depth_hypo
