@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""bench.py -- ref-views/sec (fwd+bwd) of the MVSTER cost-volume hot path on synthetic DTU-shaped tensors.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+
+One process per GPU (torch.distributed over RCCL when launched by torch.distributed.run).  A "step" is one
+forward + backward pass of the hot path over one batch of reference views at the four literal DTU stage
+shapes (1600x1184, 1 ref + 4 src views, D = 8,8,4,4, G = 8,8,4,4):
+
+  per stage: hypothesis scheduling (A5/A6) -> poses -> fused cost volume (A2) -> stub regnet (vol.sum(1), the
+  callback the reference's reg2d occupies; out of scope) -> depth regression (A4); loss = sum(attn * w);
+  backward: softmax backward -> stub regnet backward -> fused cost-volume backward (A3, fp32 atomics).
+
+Every rank works on its own batch (units = reference views, no data-path collective).  With more than one rank
+the step ends with the only exchange the reference has in training: an all-reduce of a 1,009,119-element fp32
+gradient vector (the reference model's parameter count; its DDP bucket), over RCCL/xGMI.
+
+Prints ONE JSON line on rank 0 (see README / the driver contract) with two extra objects:
+  roofline     -- dominant kernel's algorithmic HBM bytes per launch / its average duration (HIP events on the
+                  launch stream, collected over the timed steps) against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (same torch operator sequence as the reference's CPU path, kind "port")
+                  timed on this host's cores on a bounded sample (one reference view, one pass).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import deep_reconstruction_with_epipolar_lines_mvster_amd as mv           # noqa: E402
+from deep_reconstruction_with_epipolar_lines_mvster_amd import _lib      # noqa: E402
+
+# (H, W, C, G, D, intrinsics scale, split_itv)  -- DTU 1600x1184, stage_splits 8,8,4,4, group_cor_dim 8,8,4,4,
+# depth_interals_ratio 0.5,0.5,0.5,1 (scripts/train_dtu.sh:20-45 of the reference)
+DTU_STAGES = [
+    (148, 200, 64, 8, 8, 0.125, 0.5),
+    (296, 400, 32, 8, 8, 0.25, 0.5),
+    (592, 800, 16, 4, 4, 0.5, 0.5),
+    (1184, 1600, 8, 4, 4, 1.0, 1.0),
+]
+N_SRC = 4
+DEPTH_RANGE = (425.0, 935.0)
+ATTN_TEMP = 2.0
+DDP_GRAD_ELEMS = 1009119           # parameters of the reference model
+HBM_PEAK_GBS = 8000.0              # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def synth_views(B, N, H, W):
+    """pinhole f = 2890*(W/1600) px, principal point at the centre, identity rotation,
+    translation (30 v, -10 v, 0) mm for view v."""
+    mats = torch.zeros(B, N, 2, 4, 4)
+    for v in range(N):
+        K = torch.eye(4)
+        K[0, 0] = K[1, 1] = 2890.0 * W / 1600.0
+        K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+        E = torch.eye(4)
+        E[0, 3], E[1, 3] = 30.0 * v, -10.0 * v
+        mats[:, v, 0], mats[:, v, 1] = E, K
+    return mats
+
+
+def make_inputs(B, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    stages = []
+    for (H, W, C, G, D, scale, itv) in DTU_STAGES:
+        feats = [torch.randn(B, C, H, W, generator=g).to(device).requires_grad_(True) for _ in range(N_SRC + 1)]
+        mats = synth_views(B, N_SRC + 1, H, W).to(device)
+        lw = torch.randn(B, D, H, W, generator=g).to(device)
+        stages.append(dict(feats=feats, mats=mats, lw=lw, H=H, W=W, C=C, G=G, D=D, itv=itv))
+    dv = torch.tensor([list(DEPTH_RANGE)] * B).to(device)
+    return stages, dv
+
+
+def stub_regnet(vol):
+    return vol.sum(1)
+
+
+def hot_path_step(stages, dv, net, device):
+    """Forward + backward of the 4-stage cascade; returns the stage outputs."""
+    loss = None
+    prev = None
+    for k, st in enumerate(stages):
+        if k == 0:
+            hypo = mv.init_inverse_range(dv, st["D"], device, torch.float32, st["H"], st["W"])
+        else:
+            hypo = mv.schedule_inverse_range(prev["inverse_min_depth"].detach(), prev["inverse_max_depth"].detach(),
+                                             st["D"], st["H"], st["W"])
+        prev = net(st["feats"], st["mats"], hypo, stub_regnet, k, group_cor=True, group_cor_dim=st["G"],
+                   split_itv=st["itv"])
+        term = (prev["attn_weight"] * st["lw"]).sum()
+        loss = term if loss is None else loss + term
+    loss.backward()
+    for st in stages:
+        for f in st["feats"]:
+            f.grad = None
+    return prev
+
+
+# ---------------------------------------------------------------------------------- algorithmic bytes
+def algorithmic_bytes(entry, B, C, G, D, HW, S):
+    px = HW * B
+    if entry == "mvster_cost_volume_fwd":
+        return 4 * (C * px + S * C * px + D * px) + 4 * G * D * px
+    if entry == "mvster_cost_volume_bwd":
+        return 4 * (G * D * px + C * px + S * C * px + D * px) + 4 * (C * px + S * C * px)
+    if entry == "mvster_depth_regress_fwd":
+        return 4 * (D * px + D * px + px + 2 * px)
+    if entry == "mvster_softmax_bwd":
+        return 4 * 3 * D * px
+    if entry in ("mvster_init_range", "mvster_schedule_inverse_range"):
+        return 4 * D * px
+    return 0
+
+
+class LaunchTimer:
+    """Brackets every C-ABI call with HIP events on torch's current stream (the stream the kernels launch on)."""
+
+    def __init__(self):
+        self.records = defaultdict(list)
+        self.enabled = False
+        self._orig = _lib.call
+
+    def install(self):
+        orig = self._orig
+        timer = self
+
+        def timed_call(name, *args):
+            if not timer.enabled:
+                return orig(name, *args)
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            orig(name, *args)
+            b.record()
+            timer.records[(name, timer.shape_key(name, args))].append((a, b))
+
+        _lib.call = timed_call
+        mv.hotpath._lib.call = timed_call
+
+    @staticmethod
+    def shape_key(name, args):
+        if name == "mvster_cost_volume_fwd":
+            B, C, G, D, H, W = args[7:13]
+            return (B, C, G, D, H * W, args[2])
+        if name == "mvster_cost_volume_bwd":
+            B, C, G, D, H, W = args[10:16]
+            return (B, C, G, D, H * W, args[5])
+        if name == "mvster_depth_regress_fwd":
+            B, D, H, W = args[8:12]
+            return (B, 0, 0, D, H * W, 0)
+        if name == "mvster_softmax_bwd":
+            B, D, H, W = args[3:7]
+            return (B, 0, 0, D, H * W, 0)
+        if name == "mvster_init_range":
+            B, D, H, W = args[3:7]
+            return (B, 0, 0, D, H * W, 0)
+        if name == "mvster_schedule_inverse_range":
+            B, D, _, _, H, W = args[3:9]
+            return (B, 0, 0, D, H * W, 0)
+        return (0, 0, 0, 0, 0, 0)
+
+    def summary(self):
+        rows = []
+        for (name, key), evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            B, C, G, D, HW, S = key
+            nbytes = algorithmic_bytes(name, B, C, G, D, HW, S)
+            rows.append(dict(entry=name, B=B, C=C, G=G, D=D, HW=HW, S=S, launches=len(ms), avg_ms=sum(ms) / len(ms),
+                             total_ms=sum(ms), algorithmic_bytes=nbytes))
+        rows.sort(key=lambda r: -r["total_ms"])
+        return rows
+
+
+# ---------------------------------------------------------------------------------- CPU baseline (oracle, kind "port")
+def host_cores():
+    """CPU cores this process may actually use: cgroup quota, then affinity, then the box's share per GPU (16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline():
+    from oracle import mvster_oracle as orc
+    torch.set_num_threads(host_cores())
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1)
+    dv = torch.tensor([list(DEPTH_RANGE)])
+    data = []
+    for (H, W, C, G, D, scale, itv) in DTU_STAGES:
+        feats = [torch.randn(1, C, H, W, generator=g).requires_grad_(True) for _ in range(N_SRC + 1)]
+        data.append((feats, synth_views(1, N_SRC + 1, H, W), torch.randn(1, D, H, W, generator=g)))
+
+    def one_pass(stage_ids):
+        prev, loss = None, 0
+        for k in stage_ids:
+            H, W, C, G, D, scale, itv = DTU_STAGES[k]
+            feats, mats, lw = data[k]
+            if prev is None:
+                hypo = orc.init_inverse_range(dv, D, dv.device, dv.dtype, H, W)
+            else:
+                hypo = orc.schedule_inverse_range(prev["inverse_min_depth"].detach(), prev["inverse_max_depth"].detach(), D, H, W)
+            prev = orc.stage_forward(feats, mats, hypo, stub_regnet, True, group_cor=True, group_cor_dim=G, split_itv=itv,
+                                     inverse_depth=True, mono=False, attn_fuse_d=True, attn_temp=ATTN_TEMP)
+            loss = loss + (prev["attn_weight"] * lw).sum()
+        loss.backward()
+
+    one_pass([0])                      # warm the operator caches on the smallest stage (untimed)
+    t0 = time.perf_counter()
+    one_pass([0, 1, 2, 3])
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "ref-views/s", "cores": cores, "kind": "port",
+            "sample": "1 reference view (B=1), DTU 1600x1184 S=4 D=(8,8,4,4), all 4 stages fwd+bwd, 1 timed pass "
+                      "(%.1f s) of oracle/mvster_oracle.py with %d torch threads" % (dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="reference views per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+    _lib.load()
+
+    B = args.batch
+    stages, dv = make_inputs(B, seed=1234 + rank, device=device)
+    net = mv.stagenet(inverse_depth=True, mono=True, attn_fuse_d=True, attn_temp=ATTN_TEMP).train()
+    grad_vec = torch.zeros(DDP_GRAD_ELEMS, device=device) if world > 1 else None
+    timer = LaunchTimer()
+    timer.install()
+
+    def step():
+        hot_path_step(stages, dv, net, device)
+        if grad_vec is not None:
+            dist.all_reduce(grad_vec)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        rows = timer.summary()
+        dom = rows[0]
+        achieved = dom["algorithmic_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
+        kernels = [{"entry": r["entry"], "shape": "B%d C%d G%d D%d px%d S%d" % (r["B"], r["C"], r["G"], r["D"], r["HW"], r["S"]),
+                    "avg_ms": round(r["avg_ms"], 4), "launches": r["launches"],
+                    "GBps": round(r["algorithmic_bytes"] / (r["avg_ms"] * 1e-3) / 1e9, 1)} for r in rows[:8]]
+        out = {
+            "metric": "reference-views/sec (fwd+bwd), DTU 1600x1184 N=5 D=(8,8,4,4)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "ref-views/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "MVSTER cost-volume hot path fwd+bwd (stub regnet), DTU 1600x1184 stage shapes "
+                                   "148x200/296x400/592x800/1184x1600, 1 ref + 4 src views, D=(8,8,4,4), G=(8,8,4,4), "
+                                   "C=(64,32,16,8), inverse depth, attn_temp 2",
+                       "ref_views_per_gpu_per_step": B, "global_batch": B * world,
+                       "exchange": "none" if world == 1 else "all-reduce of 1,009,119 fp32 (DDP gradient bucket) per step"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "%s [B%d C%d G%d D%d px%d S%d]" % (dom["entry"], dom["B"], dom["C"], dom["G"], dom["D"],
+                                                                      dom["HW"], dom["S"]),
+                         "avg_launch_ms": round(dom["avg_ms"], 4), "launches_timed": dom["launches"],
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

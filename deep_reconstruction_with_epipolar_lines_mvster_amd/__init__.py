@@ -4,7 +4,8 @@ Drop-in for the hot-path symbols of the reference's ``models/mvs4net_utils.py`` 
 the kernels live in csrc/ behind the C ABI of include/mvster_hip.h.
 """
 from .hotpath import (homo_warping, stagenet, init_range, init_inverse_range, schedule_inverse_range,  # noqa: F401
-                      stage_poses, relative_pose, fused_cost_volume, depth_regress)
+                      stage_poses, relative_pose, fused_cost_volume, depth_regress, to_channels_last,
+                      to_planar)
 
 __all__ = ["homo_warping", "stagenet", "init_range", "init_inverse_range", "schedule_inverse_range",
-           "stage_poses", "relative_pose", "fused_cost_volume", "depth_regress"]
+           "stage_poses", "relative_pose", "fused_cost_volume", "depth_regress", "to_channels_last", "to_planar"]

@@ -22,8 +22,11 @@ PROTOTYPES = {
     "mvster_stage_poses": [_vp, _vp, _i, _i, _vp],
     "mvster_warp_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_warp_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "mvster_cost_volume_fwd": [_vp, _vpp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
-    "mvster_cost_volume_bwd": [_vp, _vp, _vp, _vp, _vpp, _i, _vp, _vp, _vp, _vpp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "mvster_nchw_to_nhwc": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "mvster_nhwc_to_nchw": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "mvster_cost_volume_fwd": [_vp, _vpp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "mvster_cost_volume_bwd": [_vp, _vp, _vp, _vp, _vpp, _i, _vp, _vp, _vp, _vpp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i,
+                               _vp],
     "mvster_depth_regress_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mvster_softmax_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvster_init_range": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
@@ -31,6 +34,8 @@ PROTOTYPES = {
 }
 
 MVSTER_OK = 0
+LAYOUT_NCHW = 0
+LAYOUT_NHWC = 1
 MVSTER_ERR_UNSUPPORTED = 3
 
 _lock = threading.Lock()

@@ -126,15 +126,228 @@ cost_volume_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__
     }
 }
 
+
+
+// Scatter-add of one lane's per-tap gradients (4 taps x C channels) with DENSE atomic wave-instructions.
+// Float atomics execute at the memory side in 64-byte requests and their rate is set by the number of
+// requests, not by the dwords each carries: letting every lane add its own tap (one dword per request)
+// costs ~16x more requests than necessary.  The wave therefore transposes through a private LDS strip:
+// each lane deposits 32 values (C = 8: 4 taps x 8 channels; C >= 16: 2 taps x 16 channels per pass) plus
+// its 4 tap offsets, then lane l of the wave adds element (l & 31) of source lane (l >> 5) + 2*iteration,
+// so that 8/16 consecutive lanes cover one tap's contiguous channels (and a tap pair x0,x0+1 one 64-byte run).
+constexpr int kStageRow = 36;   // 32 values + 4 offsets (dwords) per lane; 144 B keeps 16-byte alignment
+
+template <int C>
+__device__ __forceinline__ void dense_scatter(float (*strip)[kStageRow], int lane, const Taps& t,
+                                              const float (&dwarp)[C], float* __restrict__ gsrcb, bool live) {
+    static_assert(C == 8 || C % 16 == 0, "channel count not handled by dense_scatter");
+    const float wt[4] = {live ? t.w00 : 0.0f, live ? t.w01 : 0.0f, live ? t.w10 : 0.0f, live ? t.w11 : 0.0f};
+    float4* __restrict__ mine = reinterpret_cast<float4*>(strip[lane]);
+    reinterpret_cast<int4*>(strip[lane])[8] = make_int4(t.o00 * C, t.o01 * C, t.o10 * C, t.o11 * C);
+    if constexpr (C == 8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mine[2 * k + 0] = make_float4(dwarp[0] * wt[k], dwarp[1] * wt[k], dwarp[2] * wt[k], dwarp[3] * wt[k]);
+            mine[2 * k + 1] = make_float4(dwarp[4] * wt[k], dwarp[5] * wt[k], dwarp[6] * wt[k], dwarp[7] * wt[k]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int e = it * 64 + lane;
+            const int sl = e >> 5, slot = e & 31;
+            const float v = strip[sl][slot];
+            const int off = reinterpret_cast<const int*>(strip[sl])[32 + (slot >> 3)];
+            if (v != 0.0f) atomicAdd(gsrcb + off + (slot & 7), v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+#pragma unroll
+            for (int cb = 0; cb < C / 16; ++cb) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float wk = wt[2 * row + u];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int c = 16 * cb + 4 * q4;
+                        mine[4 * u + q4] = make_float4(dwarp[c] * wk, dwarp[c + 1] * wk, dwarp[c + 2] * wk, dwarp[c + 3] * wk);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+                for (int it = 0; it < 32; ++it) {
+                    const int e = it * 64 + lane;
+                    const int sl = e >> 5, slot = e & 31;
+                    const float v = strip[sl][slot];
+                    const int off = reinterpret_cast<const int*>(strip[sl])[32 + 2 * row + (slot >> 4)];
+                    if (v != 0.0f) atomicAdd(gsrcb + off + 16 * cb + (slot & 15), v);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- backward, channels-last features
+template <int C, int G, int D, int DPL>
+__global__ void __launch_bounds__(kBlock)
+cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restrict__ vol,
+                            const float* __restrict__ wsum, const float* __restrict__ ref, SrcPtrs srcs,
+                            const float* __restrict__ pose, const float* __restrict__ hypo, float* __restrict__ gref,
+                            GradPtrs gsrcs, VolumeDims dm) {
+    constexpr int CPG = C / G;
+    constexpr int C4 = C / 4;
+    constexpr int DL = D / DPL;
+    constexpr int PXB = kBlock / DL;
+    __shared__ __attribute__((aligned(16))) float stage[kBlock / kWave][kWave][kStageRow];   // 36 KiB, wave-private strips
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    if (tile >= dm.ntiles) return;
+    const int b = blockIdx.y;
+    const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
+    const int dl = threadIdx.x % DL, pl = threadIdx.x / DL;
+    const int praw = tile * PXB + pl;
+    const bool live = praw < HW;
+    const int p = live ? praw : HW - 1;
+    const int y = p / dm.W, x = p - y * dm.W;
+    const float fx = (float)x, fy = (float)y;
+    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+    const float inv_tc = 1.0f / (dm.temp * dm.sqrt_c);
+
+    const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C);
+    float hyp[DPL], gd[G][DPL], godot[DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        const int d = dl * DPL + j;
+        hyp[j] = hypo[((size_t)b * D + d) * HW + p];
+        const float rden = 1.0f / wsum[((size_t)b * D + d) * HW + p];
+        godot[j] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const size_t at = (((size_t)b * G + g) * D + d) * HW + p;
+            gd[g][j] = live ? gvol[at] * rden : 0.0f;
+            godot[j] = fmaf(gd[g][j], vol[at], godot[j]);
+        }
+    }
+    float dref[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dref[c] = 0.0f;
+
+    for (int s = 0; s < dm.S; ++s) {
+        const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C;
+        float* __restrict__ gsrcb = gsrcs.p[s] + (size_t)b * HWs * C;
+        const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
+        const Ray ray = rotate_pixel(q, fx, fy);
+        Taps taps[DPL];
+        float warped[C][DPL], cor[G][DPL];
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            taps[j] = project_taps(q, ray, hyp[j], dm.Hs, dm.Ws, half_w, half_h);
+            const Taps& t = taps[j];
+            const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
+            const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
+            const float4* __restrict__ p10 = reinterpret_cast<const float4*>(srcb + (size_t)t.o10 * C);
+            const float4* __restrict__ p11 = reinterpret_cast<const float4*>(srcb + (size_t)t.o11 * C);
+            float cg[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) cg[g] = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) {
+                const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
+                const float4 r = refp[c4];
+                warped[4 * c4 + 0][j] = fmaf(dq.x, t.w11, fmaf(cq.x, t.w10, fmaf(bq.x, t.w01, a.x * t.w00)));
+                warped[4 * c4 + 1][j] = fmaf(dq.y, t.w11, fmaf(cq.y, t.w10, fmaf(bq.y, t.w01, a.y * t.w00)));
+                warped[4 * c4 + 2][j] = fmaf(dq.z, t.w11, fmaf(cq.z, t.w10, fmaf(bq.z, t.w01, a.z * t.w00)));
+                warped[4 * c4 + 3][j] = fmaf(dq.w, t.w11, fmaf(cq.w, t.w10, fmaf(bq.w, t.w01, a.w * t.w00)));
+                cg[(4 * c4 + 0) / CPG] = fmaf(warped[4 * c4 + 0][j], r.x, cg[(4 * c4 + 0) / CPG]);
+                cg[(4 * c4 + 1) / CPG] = fmaf(warped[4 * c4 + 1][j], r.y, cg[(4 * c4 + 1) / CPG]);
+                cg[(4 * c4 + 2) / CPG] = fmaf(warped[4 * c4 + 2][j], r.z, cg[(4 * c4 + 2) / CPG]);
+                cg[(4 * c4 + 3) / CPG] = fmaf(warped[4 * c4 + 3][j], r.w, cg[(4 * c4 + 3) / CPG]);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) cor[g][j] = cg[g] * (1.0f / CPG);
+        }
+        float a[DPL], m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            float sg = cor[0][j];
+#pragma unroll
+            for (int g = 1; g < G; ++g) sg += cor[g][j];
+            a[j] = sg / dm.temp;
+            m = fmaxf(m, a[j]);
+        }
+        m = group_max<DL>(m);
+        float e[DPL], sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            e[j] = expf(a[j] - m);
+            sum += e[j];
+        }
+        sum = group_sum<DL>(sum);
+        float what[DPL], dw[DPL], sdot = 0.0f;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            what[j] = e[j] / sum;
+            float acc = -godot[j];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc = fmaf(gd[g][j], cor[g][j], acc);
+            dw[j] = acc;
+            sdot = fmaf(what[j], dw[j], sdot);
+        }
+        sdot = group_sum<DL>(sdot);
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            const float da = what[j] * (dw[j] - sdot) * inv_tc;
+            const float w = what[j] / dm.sqrt_c;
+            float dwarp[C];
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) {
+                const float4 r = refp[c4];
+                const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * c4 + i;
+                    const float dcor = fmaf(gd[c / CPG][j], w, da) * (1.0f / CPG);
+                    dref[c] = fmaf(dcor, warped[c][j], dref[c]);
+                    dwarp[c] = dcor * rr[i];
+                }
+            }
+            dense_scatter<C>(stage[threadIdx.x >> 6], threadIdx.x & 63, taps[j], dwarp, gsrcb, live);
+        }
+    }
+    float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C);
+#pragma unroll
+    for (int c4 = 0; c4 < C4; ++c4) {
+        float4 v;
+        v.x = group_sum<DL>(dref[4 * c4 + 0]);
+        v.y = group_sum<DL>(dref[4 * c4 + 1]);
+        v.z = group_sum<DL>(dref[4 * c4 + 2]);
+        v.w = group_sum<DL>(dref[4 * c4 + 3]);
+        if (live && dl == 0) grefp[c4] = v;
+    }
+}
+
 template <int CPG, int G, int D, int DPL>
 static int launch_bwd(const float* gvol, const float* vol, const float* wsum, const float* ref, const SrcPtrs& srcs,
                       const float* pose, const float* hypo, float* gref, const GradPtrs& gsrcs, int B, VolumeDims dm,
-                      hipStream_t st) {
+                      int layout, hipStream_t st) {
     constexpr int PXB = kBlock / (D / DPL);
     dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
-    hipLaunchKernelGGL((cost_volume_bwd_kernel<CPG, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol, wsum, ref, srcs,
-                       pose, hypo, gref, gsrcs, dm);
+    if (layout == MVSTER_LAYOUT_NHWC)
+        hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
+                           ref, srcs, pose, hypo, gref, gsrcs, dm);
+    else
+        hipLaunchKernelGGL((cost_volume_bwd_kernel<CPG, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol, wsum, ref,
+                           srcs, pose, hypo, gref, gsrcs, dm);
     return launch_status();
 }
 
@@ -143,12 +356,12 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
 extern "C" int mvster_cost_volume_bwd(const float* gvol, const float* vol, const float* wsum, const float* ref,
                                       const float* const* srcs, int S, const float* pose, const float* hypo,
                                       float* gref, float* const* gsrcs, int B, int C, int G, int D, int H, int W,
-                                      int Hs, int Ws, float attn_temp, mvster_stream_t stream) {
+                                      int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(gvol); MVSTER_REQUIRE_PTR(vol); MVSTER_REQUIRE_PTR(wsum); MVSTER_REQUIRE_PTR(ref);
     MVSTER_REQUIRE_PTR(srcs); MVSTER_REQUIRE_PTR(pose); MVSTER_REQUIRE_PTR(hypo); MVSTER_REQUIRE_PTR(gref);
     MVSTER_REQUIRE_PTR(gsrcs);
-    if (int rc = check_volume(S, B, C, G, D, H, W, Hs, Ws, attn_temp)) return rc;
+    if (int rc = check_volume(S, B, C, G, D, H, W, Hs, Ws, attn_temp, layout)) return rc;
     SrcPtrs sp{};
     GradPtrs gp{};
     for (int s = 0; s < S; ++s) {
@@ -170,11 +383,11 @@ extern "C" int mvster_cost_volume_bwd(const float* gvol, const float* vol, const
     if (cpg == CPG_ && G == G_) {                                                                                     \
         if constexpr (CPG_ * G_ <= kMaxWideChannels) {                                                                \
             if (D == 4 && wide)                                                                                       \
-                return launch_bwd<CPG_, G_, 4, 4>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, st);         \
+                return launch_bwd<CPG_, G_, 4, 4>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, layout, st);         \
         }                                                                                                             \
-        if (D == 4) return launch_bwd<CPG_, G_, 4, 1>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, st);     \
-        if (D == 8) return launch_bwd<CPG_, G_, 8, 1>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, st);     \
-        if (D == 16) return launch_bwd<CPG_, G_, 16, 1>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, st);   \
+        if (D == 4) return launch_bwd<CPG_, G_, 4, 1>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, layout, st);     \
+        if (D == 8) return launch_bwd<CPG_, G_, 8, 1>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, layout, st);     \
+        if (D == 16) return launch_bwd<CPG_, G_, 16, 1>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, layout, st);   \
     }
     MVSTER_FOR_SHAPES(X)
 #undef X

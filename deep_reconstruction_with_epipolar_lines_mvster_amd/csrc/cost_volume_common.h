@@ -42,7 +42,8 @@ inline bool pick_pixel_per_lane(int B, int HW, int C, int D) {
     return D == 4 && C <= kMaxWideChannels && ((long long)B * HW) / kWave >= kMinPixelWaves;
 }
 
-inline int check_volume(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, float temp) {
+inline int check_volume(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, float temp, int layout) {
+    MVSTER_REQUIRE_SHAPE(layout == MVSTER_LAYOUT_NCHW || layout == MVSTER_LAYOUT_NHWC);
     MVSTER_REQUIRE_SHAPE(B > 0 && C > 0 && G > 0 && D > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && S > 0);
     MVSTER_REQUIRE_SHAPE(B <= 65535 && C % G == 0 && temp != 0.0f);
     MVSTER_REQUIRE_SHAPE((long long)H * W <= kMaxPlane && (long long)Hs * Ws <= kMaxPlane);

@@ -113,14 +113,131 @@ cost_volume_fwd_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float*
     }
 }
 
+
+// ------------------------------------------------------------------------------- forward, channels-last features
+// Same decomposition, but every feature map is [B,H,W,C] (torch channels_last): one bilinear tap is C
+// contiguous floats, fetched as C/4 16-byte loads.  The gather then costs one or two 64-byte sectors per
+// tap pair however incoherent neighbouring pixels' depths are, instead of one sector per (tap, channel)
+// as with NCHW planes -- this is the layout the training/inference path uses (hotpath.py converts once per
+// stage, or takes channels_last tensors as they are).
+template <int C, int G, int D, int DPL>
+__global__ void __launch_bounds__(kBlock)
+cost_volume_fwd_nhwc_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float* __restrict__ pose,
+                            const float* __restrict__ hypo, float* __restrict__ vol, float* __restrict__ wsum,
+                            VolumeDims dm) {
+    constexpr int CPG = C / G;
+    constexpr int C4 = C / 4;
+    constexpr int DL = D / DPL;
+    constexpr int PXB = kBlock / DL;
+    constexpr bool kRefInRegs = (C <= 16);
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    if (tile >= dm.ntiles) return;
+    const int b = blockIdx.y;
+    const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
+    const int dl = threadIdx.x % DL, pl = threadIdx.x / DL;
+    const int praw = tile * PXB + pl;
+    const bool live = praw < HW;
+    const int p = live ? praw : HW - 1;
+    const int y = p / dm.W, x = p - y * dm.W;
+    const float fx = (float)x, fy = (float)y;
+    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+
+    const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C);
+    float4 refv[kRefInRegs ? C4 : 1];
+    if constexpr (kRefInRegs) {
+#pragma unroll
+        for (int q = 0; q < C4; ++q) refv[q] = refp[q];
+    }
+    float hyp[DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) hyp[j] = hypo[((size_t)b * D + dl * DPL + j) * HW + p];
+
+    float den[DPL], num[G][DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        den[j] = 1e-8f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) num[g][j] = 0.0f;
+    }
+
+    for (int s = 0; s < dm.S; ++s) {
+        const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C;
+        const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
+        const Ray ray = rotate_pixel(q, fx, fy);
+        float cor[G][DPL];
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            const Taps t = project_taps(q, ray, hyp[j], dm.Hs, dm.Ws, half_w, half_h);
+            const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
+            const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
+            const float4* __restrict__ p10 = reinterpret_cast<const float4*>(srcb + (size_t)t.o10 * C);
+            const float4* __restrict__ p11 = reinterpret_cast<const float4*>(srcb + (size_t)t.o11 * C);
+            float cg[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) cg[g] = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) {
+                const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
+                const float4 r = kRefInRegs ? refv[kRefInRegs ? c4 : 0] : refp[c4];
+                const float w0 = fmaf(dq.x, t.w11, fmaf(cq.x, t.w10, fmaf(bq.x, t.w01, a.x * t.w00)));
+                const float w1 = fmaf(dq.y, t.w11, fmaf(cq.y, t.w10, fmaf(bq.y, t.w01, a.y * t.w00)));
+                const float w2 = fmaf(dq.z, t.w11, fmaf(cq.z, t.w10, fmaf(bq.z, t.w01, a.z * t.w00)));
+                const float w3 = fmaf(dq.w, t.w11, fmaf(cq.w, t.w10, fmaf(bq.w, t.w01, a.w * t.w00)));
+                cg[(4 * c4 + 0) / CPG] = fmaf(w0, r.x, cg[(4 * c4 + 0) / CPG]);
+                cg[(4 * c4 + 1) / CPG] = fmaf(w1, r.y, cg[(4 * c4 + 1) / CPG]);
+                cg[(4 * c4 + 2) / CPG] = fmaf(w2, r.z, cg[(4 * c4 + 2) / CPG]);
+                cg[(4 * c4 + 3) / CPG] = fmaf(w3, r.w, cg[(4 * c4 + 3) / CPG]);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) cor[g][j] = cg[g] * (1.0f / CPG);
+        }
+        float a[DPL], m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            float sg = cor[0][j];
+#pragma unroll
+            for (int g = 1; g < G; ++g) sg += cor[g][j];
+            a[j] = sg / dm.temp;
+            m = fmaxf(m, a[j]);
+        }
+        m = group_max<DL>(m);
+        float e[DPL], sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            e[j] = expf(a[j] - m);
+            sum += e[j];
+        }
+        sum = group_sum<DL>(sum);
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) {
+            const float w = (e[j] / sum) / dm.sqrt_c;
+            den[j] += w;
+#pragma unroll
+            for (int g = 0; g < G; ++g) num[g][j] += w * cor[g][j];
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        const int d = dl * DPL + j;
+#pragma unroll
+        for (int g = 0; g < G; ++g) vol[(((size_t)b * G + g) * D + d) * HW + p] = num[g][j] / den[j];
+        if (wsum != nullptr) wsum[((size_t)b * D + d) * HW + p] = den[j];
+    }
+}
+
 template <int CPG, int G, int D, int DPL>
 static int launch_fwd(const float* ref, const SrcPtrs& srcs, const float* pose, const float* hypo, float* vol,
-                      float* wsum, int B, VolumeDims dm, hipStream_t st) {
+                      float* wsum, int B, VolumeDims dm, int layout, hipStream_t st) {
     constexpr int PXB = kBlock / (D / DPL);
     dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
-    hipLaunchKernelGGL((cost_volume_fwd_kernel<CPG, G, D, DPL>), grid, dim3(kBlock), 0, st, ref, srcs, pose, hypo, vol,
-                       wsum, dm);
+    if (layout == MVSTER_LAYOUT_NHWC)
+        hipLaunchKernelGGL((cost_volume_fwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, ref, srcs,
+                           pose, hypo, vol, wsum, dm);
+    else
+        hipLaunchKernelGGL((cost_volume_fwd_kernel<CPG, G, D, DPL>), grid, dim3(kBlock), 0, st, ref, srcs, pose, hypo,
+                           vol, wsum, dm);
     return launch_status();
 }
 
@@ -128,11 +245,11 @@ static int launch_fwd(const float* ref, const SrcPtrs& srcs, const float* pose, 
 
 extern "C" int mvster_cost_volume_fwd(const float* ref, const float* const* srcs, int S, const float* pose,
                                       const float* hypo, float* vol, float* wsum, int B, int C, int G, int D, int H,
-                                      int W, int Hs, int Ws, float attn_temp, mvster_stream_t stream) {
+                                      int W, int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(ref); MVSTER_REQUIRE_PTR(srcs); MVSTER_REQUIRE_PTR(pose); MVSTER_REQUIRE_PTR(hypo);
     MVSTER_REQUIRE_PTR(vol);
-    if (int rc = check_volume(S, B, C, G, D, H, W, Hs, Ws, attn_temp)) return rc;
+    if (int rc = check_volume(S, B, C, G, D, H, W, Hs, Ws, attn_temp, layout)) return rc;
     SrcPtrs sp{};
     for (int s = 0; s < S; ++s) {
         MVSTER_REQUIRE_PTR(srcs[s]);
@@ -145,11 +262,11 @@ extern "C" int mvster_cost_volume_fwd(const float* ref, const float* const* srcs
 #define X(CPG_, G_)                                                                                          \
     if (cpg == CPG_ && G == G_) {                                                                            \
         if constexpr (CPG_ * G_ <= kMaxWideChannels) {                                                       \
-            if (D == 4 && wide) return launch_fwd<CPG_, G_, 4, 4>(ref, sp, pose, hypo, vol, wsum, B, dm, st); \
+            if (D == 4 && wide) return launch_fwd<CPG_, G_, 4, 4>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st); \
         }                                                                                                    \
-        if (D == 4) return launch_fwd<CPG_, G_, 4, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, st);            \
-        if (D == 8) return launch_fwd<CPG_, G_, 8, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, st);            \
-        if (D == 16) return launch_fwd<CPG_, G_, 16, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, st);          \
+        if (D == 4) return launch_fwd<CPG_, G_, 4, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st);            \
+        if (D == 8) return launch_fwd<CPG_, G_, 8, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st);            \
+        if (D == 16) return launch_fwd<CPG_, G_, 16, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st);          \
     }
     MVSTER_FOR_SHAPES(X)
 #undef X

@@ -19,13 +19,13 @@ import torch.nn as nn
 from . import _lib
 
 __all__ = ["homo_warping", "stagenet", "init_range", "init_inverse_range", "schedule_inverse_range",
-           "stage_poses", "relative_pose", "fused_cost_volume", "depth_regress"]
+           "stage_poses", "relative_pose", "fused_cost_volume", "depth_regress", "to_channels_last", "to_planar"]
 
 
 # ----------------------------------------------------------------------------------------------
 # plumbing
 # ----------------------------------------------------------------------------------------------
-def _need(t, name, ndim=None):
+def _need(t, name, ndim=None, keep_layout=False):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
     if not t.is_cuda:
@@ -35,6 +35,8 @@ def _need(t, name, ndim=None):
         raise RuntimeError("%s has dtype %s: the hot path computes in float32 like the reference" % (name, t.dtype))
     if ndim is not None and t.dim() != ndim:
         raise RuntimeError("%s must have %d dimensions, got shape %s" % (name, ndim, tuple(t.shape)))
+    if keep_layout and t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t                      # channels_last feature maps are consumed in place
     return t.contiguous()
 
 
@@ -137,45 +139,87 @@ def homo_warping(src_fea, src_proj, ref_proj, depth_values, vis_ETA=False, fn=No
 # ----------------------------------------------------------------------------------------------
 # A2/A3 fused cost volume
 # ----------------------------------------------------------------------------------------------
+def _is_channels_last(t):
+    """True when ``t`` [B,C,H,W] is stored as [B,H,W,C] (torch.channels_last) and NOT also plain contiguous."""
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
+def to_channels_last(t):
+    """[B,C,H,W] fp32 HIP tensor -> same logical tensor stored [B,H,W,C]; zero-copy if it already is."""
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return t
+    t = t.contiguous()
+    B, C, H, W = t.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=t.device, memory_format=torch.channels_last)
+    with _on(t.device):
+        _lib.call("mvster_nchw_to_nhwc", t.data_ptr(), out.data_ptr(), B, C, H, W, _stream(t.device))
+    return out
+
+
+def to_planar(t):
+    """channels_last [B,C,H,W] tensor -> NCHW-contiguous copy."""
+    if t.is_contiguous():
+        return t
+    B, C, H, W = t.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=t.device)
+    with _on(t.device):
+        _lib.call("mvster_nhwc_to_nchw", t.data_ptr(), out.data_ptr(), B, C, H, W, _stream(t.device))
+    return out
+
+
 class _FusedCostVolume(torch.autograd.Function):
+    """Feature maps may arrive NCHW-contiguous (the reference's FPN output) or channels_last.  The kernels
+    gather from channels-last storage: NCHW inputs are converted once per call (and their gradients converted
+    back), channels_last inputs are used in place and receive channels_last gradients."""
+
     @staticmethod
-    def forward(ctx, pose, hypo, attn_temp, G, ref, *srcs):
+    def forward(ctx, pose, hypo, attn_temp, G, layout, ref, *srcs):
         B, C, H, W = ref.shape
         D = hypo.shape[1]
         S = len(srcs)
         Hs, Ws = srcs[0].shape[-2:]
+        feats = (ref,) + tuple(srcs)
+        if layout == _lib.LAYOUT_NHWC:
+            was_cl = [_is_channels_last(f) for f in feats]
+            feats = tuple(to_channels_last(f) for f in feats)
+        else:
+            was_cl = [False] * len(feats)
+            feats = tuple(f.contiguous() for f in feats)
         vol = torch.empty(B, G, D, H, W, dtype=torch.float32, device=ref.device)
         wsum = torch.empty(B, D, H, W, dtype=torch.float32, device=ref.device)
-        pp, keep = _lib.ptr_array(srcs)
+        pp, keep = _lib.ptr_array(feats[1:])
         with _on(ref.device):
-            _lib.call("mvster_cost_volume_fwd", ref.data_ptr(), pp, S, pose.data_ptr(), hypo.data_ptr(),
-                      vol.data_ptr(), wsum.data_ptr(), B, C, G, D, H, W, Hs, Ws, float(attn_temp), _stream(ref.device))
+            _lib.call("mvster_cost_volume_fwd", feats[0].data_ptr(), pp, S, pose.data_ptr(), hypo.data_ptr(),
+                      vol.data_ptr(), wsum.data_ptr(), B, C, G, D, H, W, Hs, Ws, float(attn_temp), layout,
+                      _stream(ref.device))
         del keep
-        ctx.save_for_backward(pose, hypo, vol, wsum, ref, *srcs)
-        ctx.cfg = (float(attn_temp), int(G))
+        ctx.save_for_backward(pose, hypo, vol, wsum, *feats)
+        ctx.cfg = (float(attn_temp), int(G), int(layout), was_cl)
         return vol
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gvol):
-        pose, hypo, vol, wsum, ref = ctx.saved_tensors[:5]
-        srcs = ctx.saved_tensors[5:]
-        attn_temp, G = ctx.cfg
+        pose, hypo, vol, wsum = ctx.saved_tensors[:4]
+        feats = ctx.saved_tensors[4:]
+        attn_temp, G, layout, was_cl = ctx.cfg
+        ref, srcs = feats[0], feats[1:]
         B, C, H, W = ref.shape
         D = hypo.shape[1]
         S = len(srcs)
         Hs, Ws = srcs[0].shape[-2:]
         gvol = gvol.contiguous()
-        gref = torch.empty_like(ref)
-        gsrcs = [torch.empty_like(s) for s in srcs]
+        grads = [torch.empty_like(f) for f in feats]        # same storage layout as the kernel-side features
         pp, keep = _lib.ptr_array(srcs)
-        gp, gkeep = _lib.ptr_array(gsrcs)
+        gp, gkeep = _lib.ptr_array(grads[1:])
         with _on(ref.device):
             _lib.call("mvster_cost_volume_bwd", gvol.data_ptr(), vol.data_ptr(), wsum.data_ptr(), ref.data_ptr(), pp, S,
-                      pose.data_ptr(), hypo.data_ptr(), gref.data_ptr(), gp, B, C, G, D, H, W, Hs, Ws, attn_temp,
-                      _stream(ref.device))
+                      pose.data_ptr(), hypo.data_ptr(), grads[0].data_ptr(), gp, B, C, G, D, H, W, Hs, Ws, attn_temp,
+                      layout, _stream(ref.device))
         del keep, gkeep
-        return (None, None, None, None, gref) + tuple(gsrcs)
+        if layout == _lib.LAYOUT_NHWC:
+            grads = [g if cl else to_planar(g) for g, cl in zip(grads, was_cl)]
+        return (None, None, None, None, None) + tuple(grads)
 
 
 _FUSED_CG = {(8, 4), (16, 4), (32, 4), (64, 4), (8, 8), (16, 8), (32, 8), (64, 8)}
@@ -188,11 +232,12 @@ def fused_supported(C, G, D, S):
     return (C, G) in _FUSED_CG and D in _FUSED_D and 1 <= S <= _MAX_SRC
 
 
-def fused_cost_volume(features, pose, depth_hypo, group_cor_dim, attn_temp):
+def fused_cost_volume(features, pose, depth_hypo, group_cor_dim, attn_temp, layout="nhwc"):
     """Fused warp + group correlation + softmax-over-depth fusion -> [B,G,D,H,W] (differentiable
-    w.r.t. every feature map).  ``pose`` = stage_poses(proj_matrices)."""
-    ref = _need(features[0], "features[0]", 4)
-    srcs = [_need(f, "features[%d]" % (i + 1), 4) for i, f in enumerate(features[1:])]
+    w.r.t. every feature map).  ``pose`` = stage_poses(proj_matrices).  ``layout`` selects the kernel family:
+    "nhwc" (default; gathers from channels-last storage, converting NCHW inputs once) or "nchw" (planar gathers)."""
+    ref = _need(features[0], "features[0]", 4, keep_layout=True)
+    srcs = [_need(f, "features[%d]" % (i + 1), 4, keep_layout=True) for i, f in enumerate(features[1:])]
     hypo = _need(depth_hypo, "depth_hypo", 4).detach()
     B, C, H, W = ref.shape
     for s in srcs:
@@ -200,7 +245,8 @@ def fused_cost_volume(features, pose, depth_hypo, group_cor_dim, attn_temp):
             raise RuntimeError("all source feature maps must share [B,C] with the reference and one [Hs,Ws]")
     if hypo.shape[0] != B or tuple(hypo.shape[2:]) != (H, W):
         raise RuntimeError("depth_hypo must be [B,D,H,W] at the reference feature resolution")
-    return _FusedCostVolume.apply(pose, hypo, float(attn_temp), int(group_cor_dim), ref, *srcs)
+    lay = {"nhwc": _lib.LAYOUT_NHWC, "nchw": _lib.LAYOUT_NCHW}[layout]
+    return _FusedCostVolume.apply(pose, hypo, float(attn_temp), int(group_cor_dim), lay, ref, *srcs)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -370,8 +416,8 @@ class stagenet(nn.Module):
             raise NotImplementedError("debug bits 5-7 open interactive cv2 windows in the reference "
                                       "(models/mvs4net_utils.py:1054,1088,1117) and are not supported")
         ref_feature = features[0]
-        ref = _need(ref_feature, "features[0]", 4)
-        srcs = [_need(f, "features[%d]" % (i + 1), 4) for i, f in enumerate(features[1:])]
+        ref = _need(ref_feature, "features[0]", 4, keep_layout=True)
+        srcs = [_need(f, "features[%d]" % (i + 1), 4, keep_layout=True) for i, f in enumerate(features[1:])]
         hypo = _need(depth_hypo, "depth_hypo", 4)
         B, D, H, W = hypo.shape
         C = ref.shape[1]
@@ -385,7 +431,8 @@ class stagenet(nn.Module):
         if group_cor and self.attn_fuse_d and fused_supported(C, int(group_cor_dim), D, S):
             vol = fused_cost_volume([ref] + srcs, pose, hypo, group_cor_dim, self.attn_temp)
         else:
-            vol = self._composed_volume(ref, srcs, pose, hypo.detach(), group_cor, int(group_cor_dim))
+            vol = self._composed_volume(ref.contiguous(), [t.contiguous() for t in srcs], pose, hypo.detach(),
+                                        group_cor, int(group_cor_dim))
 
         attn_logits = regnet(vol)                                     # B D H W
         picked = depth_regress(attn_logits, hypo, self.training, self.inverse_depth, split_itv)

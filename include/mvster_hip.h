@@ -35,6 +35,9 @@ extern "C" {
 #define MVSTER_ERR_UNSUPPORTED 3    /* valid request outside what the fused kernels instantiate */
 #define MVSTER_ERR_LAUNCH 4         /* the HIP runtime rejected a launch / memset               */
 
+#define MVSTER_LAYOUT_NCHW 0        /* feature maps are [B,C,H,W] planes (the reference's layout)  */
+#define MVSTER_LAYOUT_NHWC 1        /* feature maps are [B,H,W,C] (torch channels_last storage)    */
+
 #define MVSTER_MAX_SRC_VIEWS 16     /* source views per call of the fused kernels               */
 #define MVSTER_MAX_DEPTHS 64        /* depth hypotheses per pixel (generic kernels)             */
 
@@ -62,6 +65,15 @@ int mvster_relative_pose(const float *src_proj, const float *ref_proj, float *po
 int mvster_stage_poses(const float *proj_matrices, float *pose, int B, int N, mvster_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Feature-map layout conversion, [B,C,H,W] <-> [B,H,W,C] (C % 4 == 0, else MVSTER_ERR_UNSUPPORTED).
+ * The fused cost-volume kernels gather C contiguous floats per bilinear tap from the channels-last
+ * layout; a map that already is a torch channels_last tensor needs no conversion.
+ * replaces: nothing in the reference (its FPN emits NCHW, models/mvs4net_utils.py:426-509).
+ */
+int mvster_nchw_to_nhwc(const float *src, float *dst, int B, int C, int H, int W, mvster_stream_t stream);
+int mvster_nhwc_to_nchw(const float *src, float *dst, int B, int C, int H, int W, mvster_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * A1  homo_warping: bilinear (zeros padding, align_corners=True) gather of src features at the
  * projection of every (reference pixel, depth hypothesis).
  * replaces: models/mvs4net_utils.py:21-67 (4-D src_fea branch).
@@ -82,6 +94,7 @@ int mvster_warp_bwd(const float *gout, const float *pose, const float *depth, fl
  * Never materialises the [B,C,D,H,W] warped volume.
  * replaces: models/mvs4net_utils.py:1036-1102 (the src-view loop and the normalisation).
  *   ref   : [B,C,H,W]            srcs : host array of S device pointers, each [B,C,Hs,Ws]
+ *           (layout = MVSTER_LAYOUT_NCHW) or [B,H,W,C] / [B,Hs,Ws,C] (layout = MVSTER_LAYOUT_NHWC)
  *   pose  : [B,S,12]             hypo : [B,D,H,W]
  *   vol   : [B,G,D,H,W]  fused correlation volume (regnet input)
  *   wsum  : [B,D,H,W]    1e-8 + sum_s w_s   (saved for the backward pass; may be NULL)
@@ -90,17 +103,17 @@ int mvster_warp_bwd(const float *gout, const float *pose, const float *depth, fl
  */
 int mvster_cost_volume_fwd(const float *ref, const float *const *srcs, int S, const float *pose,
                            const float *hypo, float *vol, float *wsum, int B, int C, int G, int D, int H,
-                           int W, int Hs, int Ws, float attn_temp, mvster_stream_t stream);
+                           int W, int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream);
 
 /* A3  gradient of mvster_cost_volume_fwd w.r.t. every feature map (recompute-based).
  *   gvol : [B,G,D,H,W]   vol, wsum : the forward outputs
  *   gref : [B,C,H,W] (overwritten)   gsrcs : host array of S device pointers, each [B,C,Hs,Ws]
- *   (overwritten; fp32 atomics).
+ *   (overwritten; fp32 atomics).  Feature maps AND their gradients use `layout`.
  */
 int mvster_cost_volume_bwd(const float *gvol, const float *vol, const float *wsum, const float *ref,
                            const float *const *srcs, int S, const float *pose, const float *hypo,
                            float *gref, float *const *gsrcs, int B, int C, int G, int D, int H, int W,
-                           int Hs, int Ws, float attn_temp, mvster_stream_t stream);
+                           int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * A4  post-regnet half: softmax over depth, FIRST arg-max, depth gather, confidence, next range.

@@ -53,9 +53,11 @@ def test_argument_checks_run_before_any_launch(lib):
     arr = (ctypes.c_void_p * 1)(16)
     pp = ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p))
     # C=24 is not instantiated in the fused kernels -> UNSUPPORTED, C % G != 0 -> BAD_SHAPE
-    assert lib.mvster_cost_volume_fwd(one, pp, 1, one, one, one, one, 1, 24, 8, 8, 8, 8, 8, 8, 2.0, None) == 3
-    assert lib.mvster_cost_volume_fwd(one, pp, 1, one, one, one, one, 1, 30, 8, 8, 8, 8, 8, 8, 2.0, None) == 2
-    assert lib.mvster_cost_volume_fwd(one, pp, 17, one, one, one, one, 1, 32, 8, 8, 8, 8, 8, 8, 2.0, None) == 3
+    assert lib.mvster_cost_volume_fwd(one, pp, 1, one, one, one, one, 1, 24, 8, 8, 8, 8, 8, 8, 2.0, 1, None) == 3
+    assert lib.mvster_cost_volume_fwd(one, pp, 1, one, one, one, one, 1, 30, 8, 8, 8, 8, 8, 8, 2.0, 1, None) == 2
+    assert lib.mvster_cost_volume_fwd(one, pp, 17, one, one, one, one, 1, 32, 8, 8, 8, 8, 8, 8, 2.0, 0, None) == 3
+    assert lib.mvster_cost_volume_fwd(one, pp, 1, one, one, one, one, 1, 32, 8, 8, 8, 8, 8, 8, 2.0, 7, None) == 2
+    assert lib.mvster_nchw_to_nhwc(one, one, 1, 6, 8, 8, None) == 3
 
 
 def test_cpu_tensors_are_refused_loudly():
@@ -86,5 +88,5 @@ def test_fused_support_table_matches_library(lib):
                 # S=17 > MAX -> UNSUPPORTED regardless; S=1 with a NULL src pointer -> NULL_POINTER only if supported
                 null = (ctypes.c_void_p * 1)(None)
                 npp = ctypes.cast(null, ctypes.POINTER(ctypes.c_void_p))
-                rc = lib.mvster_cost_volume_fwd(one, npp, 1, one, one, one, one, 1, C, G, D, 8, 8, 8, 8, 2.0, None)
+                rc = lib.mvster_cost_volume_fwd(one, npp, 1, one, one, one, one, 1, C, G, D, 8, 8, 8, 8, 2.0, 1, None)
                 assert (rc == 1) == rc_expected_supported, (C, G, D, rc)

@@ -282,6 +282,43 @@ def test_dtu_stage_forward_backward_vs_oracle(dev, stage):
         close(gpu_feats[i].grad, cpu_feats[i].grad, 2e-3, 1e-7, "stage%d grad feat%d" % (stage + 1, i))
 
 
+@pytest.mark.parametrize("C,G,D,H,W", [(8, 4, 4, 33, 47), (16, 4, 4, 20, 31), (32, 8, 8, 17, 23), (64, 8, 8, 9, 14),
+                                       (64, 8, 16, 7, 9), (16, 8, 4, 12, 18), (8, 8, 8, 12, 18), (64, 4, 4, 8, 10)])
+def test_layout_routes_agree(dev, C, G, D, H, W):
+    """The planar (NCHW) and channels-last (NHWC) kernel families run the same arithmetic: forward results are
+    bit-identical, gradients equal up to atomic summation order; channels_last inputs are consumed in place and get
+    channels_last gradients; the conversion kernels are exact."""
+    g = torch.Generator().manual_seed(C * 100 + D)
+    B, S = 2, 3
+    feats = [torch.randn(B, C, H, W, generator=g).to(dev) for _ in range(S + 1)]
+    mats = synth_views(B, S + 1, H, W, scale=W / 1600.0, yaw_deg=1.0).to(dev)
+    hypo = (1.0 / (1 / 700.0 + 3e-5 * (torch.arange(D).view(1, D, 1, 1) - D / 2) +
+                   2e-4 * torch.rand(B, 1, H, W, generator=g))).expand(B, D, H, W).contiguous().to(dev)
+    pose = mv.stage_poses(mats)
+    lw = torch.randn(B, G, D, H, W, generator=g).to(dev)
+    cl = mv.to_channels_last(feats[0])
+    assert cl.shape == feats[0].shape and cl.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(cl, feats[0]) and torch.equal(mv.to_planar(cl), feats[0])
+    results = {}
+    for route in ("nchw", "nhwc", "nhwc_inplace"):
+        fin = [f.clone() for f in feats]
+        if route == "nhwc_inplace":
+            fin = [f.contiguous(memory_format=torch.channels_last) for f in fin]
+        fin = [f.requires_grad_(True) for f in fin]
+        vol = mv.fused_cost_volume(fin, pose, hypo, G, 2.0, layout="nchw" if route == "nchw" else "nhwc")
+        (vol * lw).sum().backward()
+        results[route] = (vol.detach(), [f.grad for f in fin])
+        if route == "nhwc_inplace":
+            assert all(f.grad.is_contiguous(memory_format=torch.channels_last) for f in fin)
+        else:
+            assert all(f.grad.is_contiguous() for f in fin)
+    assert torch.equal(results["nchw"][0], results["nhwc"][0])
+    assert torch.equal(results["nhwc"][0], results["nhwc_inplace"][0])
+    for i in range(S + 1):
+        close(results["nhwc"][1][i], results["nchw"][1][i], 1e-5, 1e-7, "grad feat%d nhwc vs nchw" % i)
+        close(results["nhwc_inplace"][1][i], results["nchw"][1][i], 1e-5, 1e-7, "grad feat%d in-place" % i)
+
+
 def test_identical_views_reduce_to_single_view(dev):
     """Size-independent property at the full stage-4 shape: fusing S copies of one source view gives the
     single-view correlation (num/den = S w cor / (1e-8 + S w))."""
