@@ -230,6 +230,42 @@ def cpu_baseline():
                       "(%.1f s) of oracle/mvster_oracle.py with %d torch threads" % (dt, cores)}
 
 
+def device_sync(device):
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def timed_region(step, steps, warmup, device, world):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both sides;
+    returns the elapsed seconds, MAX over ranks -- the driver's timing contract."""
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    device_sync(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    device_sync(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def whole_job_rate(world, per_rank_units, steps, elapsed):
+    """ref-views/s of the whole job: every rank processed per_rank_units per step (weak scaling)."""
+    return world * per_rank_units * steps / elapsed
+
+
+def rank_seed(rank):
+    return 1234 + rank
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,7 +288,7 @@ def main():
     _lib.load()
 
     B = args.batch
-    stages, dv = make_inputs(B, seed=1234 + rank, device=device)
+    stages, dv = make_inputs(B, seed=rank_seed(rank), device=device)
     net = mv.stagenet(inverse_depth=True, mono=True, attn_fuse_d=True, attn_temp=ATTN_TEMP).train()
     grad_vec = torch.zeros(DDP_GRAD_ELEMS, device=device) if world > 1 else None
     timer = LaunchTimer()
@@ -263,24 +299,12 @@ def main():
         if grad_vec is not None:
             dist.all_reduce(grad_vec)
 
+    timer.enabled = False
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_region(step, args.steps, 0, device, world)
     timer.enabled = False
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     if rank == 0:
         rows = timer.summary()
@@ -291,7 +315,7 @@ def main():
                     "GBps": round(r["algorithmic_bytes"] / (r["avg_ms"] * 1e-3) / 1e9, 1)} for r in rows[:8]]
         out = {
             "metric": "reference-views/sec (fwd+bwd), DTU 1600x1184 N=5 D=(8,8,4,4)",
-            "value": world * B * args.steps / elapsed,
+            "value": whole_job_rate(world, B, args.steps, elapsed),
             "unit": "ref-views/s",
             "n_gpus": world,
             "steps": args.steps,

@@ -1,0 +1,74 @@
+"""CPU, gloo, world_size 2: the N>1 control path of bench.py (barrier-bracketed timing with MAX over ranks, the
+per-step gradient all-reduce, per-rank sharding of the units) without touching a GPU."""
+import os
+import socket
+import time
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+    import bench
+    dev = torch.device("cpu")
+    grad = torch.full((bench.DDP_GRAD_ELEMS,), float(rank + 1))
+    calls = {"n": 0}
+
+    def step():
+        calls["n"] += 1
+        time.sleep(0.01 * (rank + 1))          # rank 1 is the slow one
+        grad.fill_(float(rank + 1))
+        dist.all_reduce(grad)                  # the only exchange of the path: DDP's gradient bucket
+
+    elapsed = bench.timed_region(step, steps=3, warmup=1, device=dev, world=world)
+    out[rank] = dict(elapsed=elapsed, calls=calls["n"], grad=float(grad[0]), grad_last=float(grad[-1]),
+                     seed=bench.rank_seed(rank), rate=bench.whole_job_rate(world, 4, 3, elapsed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_timing_and_exchange():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    assert set(res) == {0, 1}
+    # every rank reports the SAME elapsed = max over ranks, and it covers the slow rank's 3 timed steps
+    assert res[0]["elapsed"] == res[1]["elapsed"]
+    assert res[0]["elapsed"] >= 3 * 0.02
+    # exactly warmup + steps calls per rank
+    assert res[0]["calls"] == res[1]["calls"] == 4
+    # all-reduce summed the two ranks' gradient vectors (1 + 2), over the whole 1,009,119-element bucket
+    assert res[0]["grad"] == res[1]["grad"] == 3.0 and res[0]["grad_last"] == 3.0
+    # units are sharded: each rank works on its own reference views; whole-job rate counts both ranks
+    assert res[0]["seed"] != res[1]["seed"]
+    assert abs(res[0]["rate"] - 2 * 4 * 3 / res[0]["elapsed"]) < 1e-9
+
+
+def test_algorithmic_bytes_match_survey_totals():
+    """DTU config, S=4: forward 925.9 MB, backward 1496.6 MB per reference view."""
+    import bench
+    fwd = bwd = 0
+    for (H, W, C, G, D, scale, itv) in bench.DTU_STAGES:
+        px = H * W
+        fwd += bench.algorithmic_bytes("mvster_cost_volume_fwd", 1, C, G, D, px, 4)
+        fwd += bench.algorithmic_bytes("mvster_depth_regress_fwd", 1, 0, 0, D, px, 0)
+        bwd += bench.algorithmic_bytes("mvster_cost_volume_bwd", 1, C, G, D, px, 4)
+        bwd += bench.algorithmic_bytes("mvster_softmax_bwd", 1, 0, 0, D, px, 0)
+    # SURVEY's forward total is the eval variant (+ px for the confidence map); bench prices training mode
+    fwd_eval = fwd + sum(4 * H * W for (H, W, *_rest) in bench.DTU_STAGES)
+    assert abs(fwd_eval / 1e6 - 925.9) < 0.2
+    assert abs(bwd / 1e6 - 1496.6) < 0.2
