@@ -1,0 +1,256 @@
+"""A7 -- ``MVS4net`` API shell around the HIP hot path (reference: models/MVS4Net.py:16-193).
+
+Same constructor keywords, ``forward(imgs, proj_matrices, depth_values, filename=None)`` signature, output
+dictionary and sub-module / parameter names (``feature``, ``reg``, ``mono_depth_decoder``, ``stagenet`` ...), so
+reference checkpoints load with ``strict=True`` and ``train_mvs4.py`` / ``test_mvs4.py`` run unchanged.
+
+Only the stage body is ours (``hotpath.stagenet`` + the hypothesis-scheduling kernels).  The feature pyramid,
+the 3-D regulariser and the monocular head are OUT OF SCOPE for kernels: they are
+stock ``torch.nn`` convolutions (MIOpen on ROCm), re-stated here only so that the shell is self-contained; their
+layer shapes and parameter names follow models/mvs4net_utils.py:123-130,230-256,426-509,840-882,884-926.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .hotpath import stagenet, init_range, init_inverse_range, schedule_inverse_range
+
+__all__ = ["MVS4net", "FPN4", "reg2d", "mono_depth_decoder"]
+
+
+# --------------------------------------------------------------------------------------------------
+# stock PyTorch building blocks (out of scope for HIP kernels; parameter names match the reference)
+# --------------------------------------------------------------------------------------------------
+class _ConvBNReLU2d(nn.Module):
+    """conv -> BatchNorm2d -> ReLU; attributes ``conv``/``bn`` (models/mvs4net_utils.py:230-256, gn=False)."""
+
+    def __init__(self, cin, cout, kernel, stride, padding):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel, stride=stride, padding=padding, bias=False)
+        self.bn = nn.BatchNorm2d(cout, momentum=0.1)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+
+class _ConvBNReLU3d(nn.Module):
+    """conv3d -> BatchNorm3d -> ReLU; attributes ``conv``/``bn`` (models/mvs4net_utils.py:123-130)."""
+
+    def __init__(self, cin, cout, kernel=3, stride=1, pad=1):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, kernel, stride=stride, padding=pad, bias=False)
+        self.bn = nn.BatchNorm3d(cout)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+
+def _pyramid_level(cin, cout, downsample):
+    first = _ConvBNReLU2d(cin, cout, 5, 2, 2) if downsample else _ConvBNReLU2d(cin, cout, 3, 1, 1)
+    rest = [_ConvBNReLU2d(cout, cout, 3, 1, 1) for _ in range(2 if downsample else 1)]
+    return nn.Sequential(first, *rest)
+
+
+class FPN4(nn.Module):
+    """4-level feature pyramid: 8b/4b/2b/b channels at 1/8, 1/4, 1/2, 1/1 resolution
+    (models/mvs4net_utils.py:426-509; gn=False, dcn=False -- the only reachable configuration)."""
+
+    def __init__(self, base_channels, gn=False, dcn=False):
+        super().__init__()
+        if gn or dcn:
+            raise NotImplementedError("FPN4 with GroupNorm / deformable convolution is not reachable from the reference "
+                                      "scripts (DeformConvPack is not vendored upstream)")
+        b = base_channels
+        self.base_channels = b
+        self.conv0 = _pyramid_level(3, b, downsample=False)
+        self.conv1 = _pyramid_level(b, 2 * b, downsample=True)
+        self.conv2 = _pyramid_level(2 * b, 4 * b, downsample=True)
+        self.conv3 = _pyramid_level(4 * b, 8 * b, downsample=True)
+        top = 8 * b
+        self.inner1 = nn.Conv2d(4 * b, top, 1, bias=True)
+        self.inner2 = nn.Conv2d(2 * b, top, 1, bias=True)
+        self.inner3 = nn.Conv2d(b, top, 1, bias=True)
+        self.out1 = nn.Conv2d(top, 8 * b, 1, bias=False)
+        self.out2 = nn.Conv2d(top, 4 * b, 3, padding=1, bias=False)
+        self.out3 = nn.Conv2d(top, 2 * b, 3, padding=1, bias=False)
+        self.out4 = nn.Conv2d(top, b, 3, padding=1, bias=False)
+        self.dcn = False
+        self.out_channels = [8 * b, 4 * b, 2 * b, b]
+
+    def forward(self, x):
+        skips = [self.conv0(x)]
+        for level in (self.conv1, self.conv2, self.conv3):
+            skips.append(level(skips[-1]))
+        feat = skips[3]
+        outs = {"stage1": self.out1(feat)}
+        for k, (lateral, head) in enumerate(((self.inner1, self.out2), (self.inner2, self.out3), (self.inner3, self.out4))):
+            feat = F.interpolate(feat, scale_factor=2, mode="bilinear", align_corners=True) + lateral(skips[2 - k])
+            outs["stage%d" % (k + 2)] = head(feat)
+        return outs
+
+
+def _up3d(cin, cout):
+    return nn.Sequential(
+        nn.ConvTranspose3d(cin, cout, kernel_size=(1, 3, 3), padding=(0, 1, 1), output_padding=(0, 1, 1),
+                           stride=(1, 2, 2), bias=False),
+        nn.BatchNorm3d(cout),
+        nn.ReLU(inplace=True))
+
+
+class reg2d(nn.Module):
+    """U-Net over [B,G,D,H,W] with (1,3,3) kernels -> logits [B,D,H,W] (models/mvs4net_utils.py:884-926)."""
+
+    def __init__(self, input_channel=128, base_channel=32, conv_name="ConvBnReLU3D"):
+        super().__init__()
+        if conv_name != "ConvBnReLU3D":
+            raise NotImplementedError("aggregation block %r (attention variants of the reference) is out of scope" % conv_name)
+        b = base_channel
+        flat = dict(kernel=(1, 3, 3), pad=(0, 1, 1))
+        self.conv0 = _ConvBNReLU3d(input_channel, b, **flat)
+        self.conv1 = _ConvBNReLU3d(b, 2 * b, stride=(1, 2, 2), **flat)
+        self.conv2 = _ConvBNReLU3d(2 * b, 2 * b)
+        self.conv3 = _ConvBNReLU3d(2 * b, 4 * b, stride=(1, 2, 2), **flat)
+        self.conv4 = _ConvBNReLU3d(4 * b, 4 * b)
+        self.conv5 = _ConvBNReLU3d(4 * b, 8 * b, stride=(1, 2, 2), **flat)
+        self.conv6 = _ConvBNReLU3d(8 * b, 8 * b)
+        self.conv7 = _up3d(8 * b, 4 * b)
+        self.conv9 = _up3d(4 * b, 2 * b)
+        self.conv11 = _up3d(2 * b, b)
+        self.prob = nn.Conv3d(8, 1, 1, stride=1, padding=0)      # hard-wired to 8 input channels upstream (:914)
+
+    def forward(self, x):
+        e0 = self.conv0(x)
+        e1 = self.conv2(self.conv1(e0))
+        e2 = self.conv4(self.conv3(e1))
+        y = self.conv6(self.conv5(e2))
+        y = e2 + self.conv7(y)
+        y = e1 + self.conv9(y)
+        y = e0 + self.conv11(y)
+        return self.prob(y).squeeze(1)
+
+
+class mono_depth_decoder(nn.Module):
+    """Auxiliary monocular depth head on the reference-view features (models/mvs4net_utils.py:840-882)."""
+
+    def __init__(self, mono_stg_itrpl):
+        super().__init__()
+        self.convblocks = nn.ModuleList([_ConvBNReLU2d(c, c // 2, 3, 1, 1) for c in (64, 32, 16)])
+        self.conv3x3 = nn.ModuleList([nn.Conv2d(c, 1, 3, 1, 1) for c in (64, 32, 16)])
+        self.sigmoid = nn.Sigmoid()
+        self.interpol = mono_stg_itrpl
+
+    def forward(self, outputs, d_min, d_max, debug=0):
+        lo = (1 / d_max)[:, None, None, None]
+        hi = (1 / d_min)[:, None, None, None]
+        for i in (1, 2, 3):
+            coarse = self.convblocks[i - 1](outputs["stage%d" % i]["mono_feat"])
+            coarse = F.interpolate(coarse, scale_factor=2, mode=self.interpol)
+            fine = outputs["stage%d" % (i + 1)]["mono_feat"]
+            disp = self.sigmoid(self.conv3x3[i - 1](torch.cat([coarse, fine], 1)))
+            outputs["stage%d" % (i + 1)]["mono_depth"] = (1 / (lo + (hi - lo) * disp)).squeeze(1)
+        return outputs
+
+
+# --------------------------------------------------------------------------------------------------
+# the model
+# --------------------------------------------------------------------------------------------------
+class MVS4net(nn.Module):
+    def __init__(self, arch_mode="fpn", reg_net='reg2d', num_stage=4, fpn_base_channel=8,
+                 reg_channel=8, stage_splits=[8, 8, 4, 4], depth_interals_ratio=[0.5, 0.5, 0.5, 1],
+                 group_cor=False, group_cor_dim=[8, 8, 8, 8],
+                 inverse_depth=False,
+                 agg_type='ConvBnReLU3D',
+                 dcn=False,
+                 pos_enc=0,
+                 mono=False,
+                 mono_stg_itrpl="nearest",
+                 asff=False,
+                 attn_temp=2,
+                 attn_fuse_d=True,
+                 vis_ETA=False,
+                 vis_stg_features=False,
+                 debug=0
+                 ):
+        super(MVS4net, self).__init__()
+        if arch_mode != "fpn":
+            raise NotImplementedError("only arch_mode='fpn' builds a feature net upstream (models/MVS4Net.py:45-46)")
+        if reg_net != "reg2d":
+            raise NotImplementedError("reg_net=%r: only reg2d (every reference script) is provided; reg3d is out of scope" % reg_net)
+        if asff:
+            raise NotImplementedError("ASFF feature fusion is out of scope (SURVEY.md section 2 row 6)")
+        if debug:
+            raise NotImplementedError("debug bit-masks open interactive cv2 windows upstream; not supported")
+        self.arch_mode = arch_mode
+        self.num_stage = num_stage
+        self.depth_interals_ratio = depth_interals_ratio
+        self.group_cor = group_cor
+        self.group_cor_dim = group_cor_dim
+        self.inverse_depth = inverse_depth
+        self.asff = False
+        # registration order and construction order follow models/MVS4Net.py:42-67 so that a seeded construction
+        # reproduces the reference's initial weights and state_dict key order
+        self.attn_ob = nn.ModuleList()
+        self.feature = FPN4(base_channels=fpn_base_channel, gn=False, dcn=dcn)
+        self.vis_stg_features = vis_stg_features
+        self.stagenet = stagenet(inverse_depth, mono, attn_fuse_d, vis_ETA, attn_temp, debug=debug)
+        self.stage_splits = stage_splits
+        self.reg = nn.ModuleList()
+        self.pos_enc = pos_enc
+        self.pos_enc_func = nn.ModuleList()          # never populated upstream: --pos_enc is a no-op
+        self.mono = mono
+        self.debug = debug
+        if self.mono:
+            self.mono_depth_decoder = mono_depth_decoder(mono_stg_itrpl)
+        for idx in range(num_stage):
+            in_dim = group_cor_dim[idx] if self.group_cor else self.feature.out_channels[idx]
+            self.reg.append(reg2d(input_channel=in_dim, base_channel=reg_channel, conv_name=agg_type))
+        # torch.channels_last keeps the FPN outputs in the layout the fused kernels gather from (zero-copy);
+        # off by default: identical numerics either way, the conversion kernels cost ~1 % of a step
+        self.channels_last_features = False
+
+    def forward(self, imgs, proj_matrices, depth_values, filename=None):
+        # step 1. feature extraction (stock PyTorch)
+        features = []
+        for img in imgs:
+            if self.channels_last_features:
+                img = img.contiguous(memory_format=torch.channels_last)
+            features.append(self.feature(img))
+        device, dtype = imgs[0].device, imgs[0].dtype
+
+        # step 2. coarse-to-fine stages (HIP hot path)
+        outputs = {}
+        outputs_stage = None
+        for stage_idx in range(self.num_stage):
+            key = "stage{}".format(stage_idx + 1)
+            features_stage = [feat[key] for feat in features]
+            proj_matrices_stage = proj_matrices[key]
+            B, C, H, W = features_stage[0].shape
+            D = self.stage_splits[stage_idx]
+            if stage_idx == 0:
+                if self.inverse_depth:
+                    depth_hypo = init_inverse_range(depth_values, D, device, dtype, H, W)
+                else:
+                    depth_hypo = init_range(depth_values, D, device, dtype, H, W)
+            else:
+                if not self.inverse_depth:
+                    # upstream calls schedule_range, which raises AttributeError (ndepth.device on an int,
+                    # models/mvs4net_utils.py:102): only --inverse_depth gets past stage 1 in the reference
+                    raise NotImplementedError("non-inverse depth scheduling is broken upstream "
+                                              "(models/mvs4net_utils.py:96-106); use inverse_depth=True")
+                depth_hypo = schedule_inverse_range(outputs_stage['inverse_min_depth'].detach(),
+                                                    outputs_stage['inverse_max_depth'].detach(), D, H, W)
+            outputs_stage = self.stagenet(features_stage, proj_matrices_stage, depth_hypo=depth_hypo,
+                                          regnet=self.reg[stage_idx], stage_idx=stage_idx,
+                                          group_cor=self.group_cor, group_cor_dim=self.group_cor_dim[stage_idx],
+                                          split_itv=self.depth_interals_ratio[stage_idx], fn=filename)
+            outputs[key] = outputs_stage
+
+        if self.mono and self.training:
+            outputs = self.mono_depth_decoder(outputs, depth_values[:, 0], depth_values[:, 1], self.debug)
+        return outputs
+
+    def to_channels_last(self, enabled=True):
+        """Run the feature pyramid in torch.channels_last so that its outputs feed the fused kernels in place."""
+        self.channels_last_features = bool(enabled)
+        self.feature = self.feature.to(memory_format=torch.channels_last if enabled else torch.contiguous_format)
+        return self

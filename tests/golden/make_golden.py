@@ -13,6 +13,7 @@ reference's outputs / input-gradients for the hot-path functions of SURVEY.md se
   stage_*.npz     stagenet.forward, stub regnets     (models/mvs4net_utils.py:1017-1162)
   range_*.npz     init_range / init_inverse_range / schedule_inverse_range (:69-94)
   ties.npz        arg-max tie behaviour of the post-regnet half (:1126-1130)
+  model_e2e_64.npz  MVS4net (models/MVS4Net.py:16-193) seeded construction checksums, eval + train forward, 64x64
 """
 import math
 import os
@@ -212,8 +213,91 @@ def make_ties():
              conf=out["photometric_confidence"], inv_min=out["inverse_min_depth"], inv_max=out["inverse_max_depth"])
 
 
+# ------------------------------------------------------------------ (vi) end-to-end MVS4net
+def model_inputs(B, N, H, W, gen):
+    """imgs list, proj_matrices dict stage1..4 (intrinsics scaled 1/8,1/4,1/2,1 like datasets/dataloader_eval.py:281-287),
+    depth_values [B,2]."""
+    imgs = [torch.rand(B, 3, H, W, generator=gen) for _ in range(N)]
+    full = pinhole_views(B, N, H, W, gen, baseline=25.0)
+    proj = {}
+    for k, sc in enumerate((0.125, 0.25, 0.5, 1.0)):
+        m = full.clone()
+        m[:, :, 1, :2, :] = full[:, :, 1, :2, :] * sc
+        proj["stage%d" % (k + 1)] = m
+    dv = torch.tensor([[425.0, 935.0]] * B)
+    return imgs, proj, dv
+
+
+def state_checksums(model):
+    sd = model.state_dict()
+    keys = list(sd.keys())
+    sums = torch.tensor([float(v.double().sum()) for v in sd.values()], dtype=torch.float64)
+    abss = torch.tensor([float(v.double().abs().sum()) for v in sd.values()], dtype=torch.float64)
+    return keys, sums, abss
+
+
+def make_model():
+    from models.MVS4Net import MVS4net
+    g = torch.Generator().manual_seed(601)
+    B, N, H, W = 1, 3, 64, 64
+    imgs, proj, dv = model_inputs(B, N, H, W, g)
+    kw = dict(arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8,
+              stage_splits=[8, 8, 4, 4], depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=True,
+              group_cor_dim=[8, 8, 4, 4], inverse_depth=True, agg_type="ConvBnReLU3D", dcn=False, pos_enc=0,
+              mono=True, asff=False, attn_temp=2, attn_fuse_d=True)
+    torch.manual_seed(7)
+    model = MVS4net(**kw)
+    keys, sums, abss = state_checksums(model)
+    arrays = dict(depth_values=dv, state_sum=sums, state_abs=abss,
+                  state_keys=np.array("\n".join(keys)), n_params=np.int64(sum(p.numel() for p in model.parameters())))
+    for i, im in enumerate(imgs):
+        arrays["img%d" % i] = im
+    for k, v in proj.items():
+        arrays["proj_" + k] = v
+    # An untrained network in eval mode is degenerate (BatchNorm running stats are still 0/1 and the activations
+    # decay to a uniform attention).  Warm the running statistics with 25 train-mode passes and ship them (12 KB):
+    # the test loads them into its own seeded model.
+    model.train()
+    with torch.no_grad():
+        for _ in range(25):
+            model(imgs, proj, dv)
+    bufs = {k: v for k, v in model.state_dict().items() if "running_" in k}
+    arrays["bn_keys"] = np.array("\n".join(bufs.keys()))
+    arrays["bn_values"] = torch.cat([v.reshape(-1).float() for v in bufs.values()])
+    arrays["bn_sizes"] = np.array([v.numel() for v in bufs.values()], dtype=np.int64)
+    model.eval()
+    with torch.no_grad():
+        out = model(imgs, proj, dv)
+    for k in ("stage1", "stage2", "stage3", "stage4"):
+        arrays["eval_%s_depth" % k] = out[k]["depth"]
+        arrays["eval_%s_conf" % k] = out[k]["photometric_confidence"]
+        arrays["eval_%s_attn" % k] = out[k]["attn_weight"]
+        arrays["eval_%s_hypo" % k] = out[k]["hypo_depth"]
+    model.train()
+    out = model(imgs, proj, dv)
+    lw = {k: torch.randn(out[k]["attn_weight"].shape, generator=g) for k in ("stage1", "stage2", "stage3", "stage4")}
+    loss = sum((out[k]["attn_weight"] * lw[k]).sum() for k in lw) + sum(out[k]["mono_depth"].mean() * 1e-3 for k in ("stage2", "stage3", "stage4"))
+    loss.backward()
+    for k in lw:
+        arrays["train_%s_depth" % k] = out[k]["depth"]
+        arrays["train_%s_attn" % k] = out[k]["attn_weight"]
+        arrays["loss_w_%s" % k] = lw[k]
+        if "mono_depth" in out[k]:
+            arrays["train_%s_mono" % k] = out[k]["mono_depth"]
+    arrays["train_loss"] = loss.detach()
+    gkeys = [n for n, p in model.named_parameters() if p.grad is not None]
+    arrays["grad_keys"] = np.array("\n".join(gkeys))
+    arrays["grad_abs"] = torch.tensor([float(dict(model.named_parameters())[n].grad.double().abs().sum()) for n in gkeys],
+                                      dtype=torch.float64)
+    save("model_e2e_64", **arrays)
+
+
 if __name__ == "__main__":
+    if "--model-only" in sys.argv:
+        make_model()
+        sys.exit(0)
     make_warp()
     make_stages()
     make_ranges()
     make_ties()
+    make_model()
