@@ -120,6 +120,31 @@ def algorithmic_bytes(entry, B, C, G, D, HW, S):
     return 0
 
 
+def kernel_symbol(entry, B, C, G, D, HW):
+    """Name of the gfx950 kernel an ABI entry point launches for this shape (mirrors pick_pixel_per_lane() in
+    csrc/cost_volume_common.h), as rocprofv3 prints it -- used to look the launch up in the PMC summary."""
+    if entry in ("mvster_cost_volume_fwd", "mvster_cost_volume_bwd"):
+        wide = D == 4 and C <= 16 and (B * HW) // 64 >= 8192
+        return "cost_volume_%s_nhwc_kernel<%d, %d, %d, %d>" % (entry[-3:], C, G, D, D if wide else 1)
+    return entry.replace("mvster_", "") + "_kernel"
+
+
+def pmc_traffic(symbol, path=None):
+    """HBM bytes per launch of `symbol` from the newest committed PMC summary (tools/pmc_summary.py: separate
+    rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE of this same bench command, gfx950 corrections applied).
+    None when no summary covers the kernel."""
+    import glob
+    files = [path] if path else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    for f in reversed(files):
+        try:
+            entry = json.load(open(f)).get(symbol)
+        except (OSError, ValueError):
+            continue
+        if entry and "hbm_bytes_per_launch" in entry:
+            return entry["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), entry
+    return None, None, None
+
+
 class LaunchTimer:
     """Brackets every C-ABI call with HIP events on torch's current stream (the stream the kernels launch on)."""
 
@@ -313,6 +338,8 @@ def main():
         kernels = [{"entry": r["entry"], "shape": "B%d C%d G%d D%d px%d S%d" % (r["B"], r["C"], r["G"], r["D"], r["HW"], r["S"]),
                     "avg_ms": round(r["avg_ms"], 4), "launches": r["launches"],
                     "GBps": round(r["algorithmic_bytes"] / (r["avg_ms"] * 1e-3) / 1e9, 1)} for r in rows[:8]]
+        symbol = kernel_symbol(dom["entry"], dom["B"], dom["C"], dom["G"], dom["D"], dom["HW"])
+        traffic, traffic_src, pmc = pmc_traffic(symbol) if B == 4 else (None, None, None)
         out = {
             "metric": "reference-views/sec (fwd+bwd), DTU 1600x1184 N=5 D=(8,8,4,4)",
             "value": whole_job_rate(world, B, args.steps, elapsed),
@@ -332,9 +359,14 @@ def main():
                        "ref_views_per_gpu_per_step": B, "global_batch": B * world,
                        "exchange": "none" if world == 1 else "all-reduce of 1,009,119 fp32 (DDP gradient bucket) per step"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "%s [B%d C%d G%d D%d px%d S%d]" % (dom["entry"], dom["B"], dom["C"], dom["G"], dom["D"],
-                                                                      dom["HW"], dom["S"]),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src and (traffic_src + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                                                            "separate passes of this command (B=4), bytes = 2*FETCH_KiB*1024 + "
+                                                            "WRITE_KiB*1024 (gfx950 FETCH_SIZE halving verified on kernels "
+                                                            "with known byte counts)"),
+                         "atomic_requests_per_launch": pmc and pmc.get("TCC_EA0_ATOMIC_sum_avg"),
+                         "kernel": "%s = %s [B%d C%d G%d D%d px%d S%d]" % (dom["entry"], symbol, dom["B"], dom["C"], dom["G"],
+                                                                          dom["D"], dom["HW"], dom["S"]),
                          "avg_launch_ms": round(dom["avg_ms"], 4), "launches_timed": dom["launches"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]},
             "kernels": kernels,
