@@ -141,7 +141,8 @@ template <int C>
 __device__ __forceinline__ void dense_scatter(float (*strip)[kStageRow], int lane, const Taps& t,
                                               const float (&dwarp)[C], float* __restrict__ gsrcb, bool live) {
     static_assert(C == 8 || C % 16 == 0, "channel count not handled by dense_scatter");
-    const float wt[4] = {live ? t.w00 : 0.0f, live ? t.w01 : 0.0f, live ? t.w10 : 0.0f, live ? t.w11 : 0.0f};
+    const float wt[4] = {live ? masked_weight(t, 0) : 0.0f, live ? masked_weight(t, 1) : 0.0f,
+                         live ? masked_weight(t, 2) : 0.0f, live ? masked_weight(t, 3) : 0.0f};
     float4* __restrict__ mine = reinterpret_cast<float4*>(strip[lane]);
     reinterpret_cast<int4*>(strip[lane])[8] = make_int4(t.o00 * C, t.o01 * C, t.o10 * C, t.o11 * C);
     if constexpr (C == 8) {
@@ -197,6 +198,59 @@ __device__ __forceinline__ void dense_scatter(float (*strip)[kStageRow], int lan
     }
 }
 
+
+// ---- C = 8, one lane per pixel: merge the D hypotheses of a pixel before touching memory ------------------------
+// At the fine stages the hypotheses of one pixel project a fraction of a pixel apart, so their 2x2 footprints share
+// 64-byte lines; adding each hypothesis separately issues one atomic request per (hypothesis, row, line).
+// Every lane therefore owns a 2-row x 4-pixel x 8-channel window (two aligned 64-byte lines per row) in its
+// LDS strip, accumulates the hypotheses that fall inside it with plain LDS read-modify-writes, and the wave flushes
+// windows cooperatively: lane l adds dword l of the window (row l>>5), so one wave-instruction covers the four lines
+// of one source lane.  A hypothesis that leaves the window (other row, > 2 px away) first triggers a flush of that
+// lane's window (wave-uniform branch on __any), then re-bases it.
+constexpr int kWinRow = 68;        // 64 window dwords + base offset + flush flag (+2 pad: 272 B, 16-byte aligned)
+
+__device__ __forceinline__ void window_zero(float* __restrict__ mine) {
+    float4* __restrict__ w4 = reinterpret_cast<float4*>(mine);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w4[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// adds the window of every source lane whose flag is set; all 64 lanes of the wave must call it
+__device__ __forceinline__ void window_flush(float (*strip)[kWinRow], int lane, float* __restrict__ gsrcb, int row_stride) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int in_row = lane & 31, dy = lane >> 5;
+    for (int sl = 0; sl < kWave; ++sl) {
+        const int2 meta = *reinterpret_cast<const int2*>(&strip[sl][64]);      // same address in every lane: broadcast
+        if (__builtin_amdgcn_readfirstlane(meta.y) == 0) continue;            // wave-uniform
+        const float v = strip[sl][lane];
+        if (v != 0.0f) atomicAdd(gsrcb + (meta.x + dy * row_stride + in_row), v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// accumulate one hypothesis (4 taps x 8 channels) into the lane's window at pixel offset k (0..2)
+__device__ __forceinline__ void window_add(float* __restrict__ mine, int k, const Taps& t, const float (&dwarp)[8]) {
+    float4* __restrict__ w4 = reinterpret_cast<float4*>(mine);
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+        const float wgt = masked_weight(t, tap);
+        if (wgt != 0.0f) {
+            const int q = (((tap >> 1) * 4) + k + (tap & 1)) * 2;
+            float4 a = w4[q], b = w4[q + 1];
+            a.x = fmaf(dwarp[0], wgt, a.x); a.y = fmaf(dwarp[1], wgt, a.y);
+            a.z = fmaf(dwarp[2], wgt, a.z); a.w = fmaf(dwarp[3], wgt, a.w);
+            b.x = fmaf(dwarp[4], wgt, b.x); b.y = fmaf(dwarp[5], wgt, b.y);
+            b.z = fmaf(dwarp[6], wgt, b.z); b.w = fmaf(dwarp[7], wgt, b.w);
+            w4[q] = a;
+            w4[q + 1] = b;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- backward, channels-last features
 template <int C, int G, int D, int DPL>
 __global__ void __launch_bounds__(kBlock)
@@ -208,7 +262,9 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
     constexpr int C4 = C / 4;
     constexpr int DL = D / DPL;
     constexpr int PXB = kBlock / DL;
-    __shared__ __attribute__((aligned(16))) float stage[kBlock / kWave][kWave][kStageRow];   // 36 KiB, wave-private strips
+    constexpr bool kMergeDepths = (C == 8 && DPL > 1);     // window merge of the hypotheses of a pixel (see above)
+    constexpr int kRow = kMergeDepths ? kWinRow : kStageRow;
+    __shared__ __attribute__((aligned(16))) float stage[kBlock / kWave][kWave][kRow];   // wave-private strips
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     if (tile >= dm.ntiles) return;
     const int b = blockIdx.y;
@@ -303,6 +359,11 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
             sdot = fmaf(what[j], dw[j], sdot);
         }
         sdot = group_sum<DL>(sdot);
+        const int lane = threadIdx.x & 63;
+        [[maybe_unused]] bool have = false;
+        [[maybe_unused]] int xb = 0, yb = 0;
+        [[maybe_unused]] const int row_stride = dm.Ws * C;
+        if constexpr (kMergeDepths) window_zero(stage[threadIdx.x >> 6][lane]);
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
             const float da = what[j] * (dw[j] - sdot) * inv_tc;
@@ -320,7 +381,40 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
                     dwarp[c] = dcor * rr[i];
                 }
             }
-            dense_scatter<C>(stage[threadIdx.x >> 6], threadIdx.x & 63, taps[j], dwarp, gsrcb, live);
+            if constexpr (kMergeDepths) {
+                float (*strip)[kRow] = stage[threadIdx.x >> 6];
+                float* __restrict__ mine = strip[lane];
+                const Taps& t = taps[j];
+                const bool active = live && t.mask != 0;
+                const int k = t.ix - xb;
+                const bool fits = have && t.iy == yb && k >= 0 && k <= 2;
+                const bool spill = active && have && !fits;
+                if (__any(spill)) {
+                    *reinterpret_cast<int2*>(&mine[64]) = make_int2((yb * dm.Ws + xb) * C, spill ? 1 : 0);
+                    window_flush(strip, lane, gsrcb, row_stride);
+                    if (spill) {
+                        window_zero(mine);
+                        have = false;
+                    }
+                }
+                if (active) {
+                    if (!have) {
+                        // leave room in the direction the later hypotheses move along the epipolar line
+                        const bool leftward = taps[DPL - 1].ix < taps[0].ix;
+                        xb = leftward ? (((t.ix + 1) & ~1) - 2) : (t.ix & ~1);
+                        yb = t.iy;
+                        have = true;
+                    }
+                    window_add(mine, t.ix - xb, t, dwarp);
+                }
+            } else {
+                dense_scatter<C>(stage[threadIdx.x >> 6], lane, taps[j], dwarp, gsrcb, live);
+            }
+        }
+        if constexpr (kMergeDepths) {
+            float (*strip)[kRow] = stage[threadIdx.x >> 6];
+            *reinterpret_cast<int2*>(&strip[lane][64]) = make_int2((yb * dm.Ws + xb) * C, have ? 1 : 0);
+            window_flush(strip, lane, gsrcb, row_stride);
         }
     }
     float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C);

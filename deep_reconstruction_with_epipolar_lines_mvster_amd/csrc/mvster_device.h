@@ -54,7 +54,16 @@ __device__ __forceinline__ Ray rotate_pixel(const Pose& q, float x, float y) {
 struct Taps {
     int o00, o01, o10, o11;      // (y0,x0) (y0,x1) (y1,x0) (y1,x1); always inside the plane
     float w00, w01, w10, w11;
+    int ix, iy;                  // floor of the sample position (limited to [-2, size+1]); tap (dy,dx) = (iy+dy, ix+dx)
+    int mask;                    // bit (2*dy+dx) set when that tap lies inside the source map
 };
+
+// Backward weight of tap k: zero unless the tap is inside the map.  (A NaN sample position keeps NaN weights in
+// the forward pass so that NaN propagates like in the reference; its backward scatters nothing, as grid_sample's.)
+__device__ __forceinline__ float masked_weight(const Taps& t, int k) {
+    const float w = k == 0 ? t.w00 : k == 1 ? t.w01 : k == 2 ? t.w10 : t.w11;
+    return (t.mask >> k) & 1 ? w : 0.0f;
+}
 
 // Projection of (pixel ray, depth) into the source view and the bilinear footprint there.
 //   models/mvs4net_utils.py:43-52  p = ray*depth + trans (separately rounded), z==0 -> 1e-9,
@@ -98,6 +107,9 @@ __device__ __forceinline__ Taps project_taps(const Pose& q, const Ray& r, float 
     t.w01 = ((x1in & y0in) | (ne != ne)) ? ne : 0.0f;
     t.w10 = ((x0in & y1in) | (sw != sw)) ? sw : 0.0f;
     t.w11 = ((x1in & y1in) | (se != se)) ? se : 0.0f;
+    t.ix = (int)fminf(fmaxf(xw, -2.0f), wmax + 1.0f);
+    t.iy = (int)fminf(fmaxf(yn, -2.0f), hmax + 1.0f);
+    t.mask = (int)(x0in & y0in) | ((int)(x1in & y0in) << 1) | ((int)(x0in & y1in) << 2) | ((int)(x1in & y1in) << 3);
     return t;
 }
 
@@ -112,10 +124,11 @@ __device__ __forceinline__ float sample(const float* __restrict__ plane, const T
 
 // Scatter-add of one channel's gradient onto the four taps (skips masked taps).
 __device__ __forceinline__ void scatter(float* __restrict__ plane, const Taps& t, float g) {
-    if (t.w00 != 0.0f) atomicAdd(plane + t.o00, g * t.w00);
-    if (t.w01 != 0.0f) atomicAdd(plane + t.o01, g * t.w01);
-    if (t.w10 != 0.0f) atomicAdd(plane + t.o10, g * t.w10);
-    if (t.w11 != 0.0f) atomicAdd(plane + t.o11, g * t.w11);
+    const float w0 = masked_weight(t, 0), w1 = masked_weight(t, 1), w2 = masked_weight(t, 2), w3 = masked_weight(t, 3);
+    if (w0 != 0.0f) atomicAdd(plane + t.o00, g * w0);
+    if (w1 != 0.0f) atomicAdd(plane + t.o01, g * w1);
+    if (w2 != 0.0f) atomicAdd(plane + t.o10, g * w2);
+    if (w3 != 0.0f) atomicAdd(plane + t.o11, g * w3);
 }
 
 // Reductions over the LANES consecutive lanes (LANES a power of two <= 64) that share one pixel.
