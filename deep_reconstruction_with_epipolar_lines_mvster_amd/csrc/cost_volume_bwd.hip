@@ -199,54 +199,71 @@ __device__ __forceinline__ void dense_scatter(float (*strip)[kStageRow], int lan
 }
 
 
-// ---- C = 8, one lane per pixel: merge the D hypotheses of a pixel before touching memory ------------------------
+// ---- C <= 16, one lane per pixel: merge the D hypotheses of a pixel before touching memory ---------------------
 // At the fine stages the hypotheses of one pixel project a fraction of a pixel apart, so their 2x2 footprints share
 // 64-byte lines; adding each hypothesis separately issues one atomic request per (hypothesis, row, line).
-// Every lane therefore owns a 2-row x 4-pixel x 8-channel window (two aligned 64-byte lines per row) in its
+// Every lane therefore owns a 2-row x 4-pixel x C-channel window (whole 64-byte lines) in its
 // LDS strip, accumulates the hypotheses that fall inside it with plain LDS read-modify-writes, and the wave flushes
-// windows cooperatively: lane l adds dword l of the window (row l>>5), so one wave-instruction covers the four lines
-// of one source lane.  A hypothesis that leaves the window (other row, > 2 px away) first triggers a flush of that
+// windows cooperatively: lane l adds dword l (+64, ...) of the window, so one wave-instruction covers whole lines of
+// one source lane.  A hypothesis that leaves the window (other row, > 2 px away) first triggers a flush of that
 // lane's window (wave-uniform branch on __any), then re-bases it.
-constexpr int kWinRow = 68;        // 64 window dwords + base offset + flush flag (+2 pad: 272 B, 16-byte aligned)
+template <int C>
+struct Window {                                  // 2 rows x 4 pixels x C channels per lane
+    static constexpr int kRowDwords = 4 * C;     // one window row: 128 B (C=8, two lines) / 256 B (C=16, four lines)
+    static constexpr int kDwords = 2 * kRowDwords;
+    static constexpr int kStrip = kDwords + 4;   // + base offset + flush flag (+2 pad, keeps 16-byte alignment)
+    static constexpr int kAlign = 16 / C;        // pixels per 64-byte line: window base is line-aligned in x
+};
 
+template <int C>
 __device__ __forceinline__ void window_zero(float* __restrict__ mine) {
     float4* __restrict__ w4 = reinterpret_cast<float4*>(mine);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) w4[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int q = 0; q < Window<C>::kDwords / 4; ++q) w4[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // adds the window of every source lane whose flag is set; all 64 lanes of the wave must call it
-__device__ __forceinline__ void window_flush(float (*strip)[kWinRow], int lane, float* __restrict__ gsrcb, int row_stride) {
+template <int C>
+__device__ __forceinline__ void window_flush(float (*strip)[Window<C>::kStrip], int lane, float* __restrict__ gsrcb,
+                                             int row_stride) {
+    using Wn = Window<C>;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int in_row = lane & 31, dy = lane >> 5;
     for (int sl = 0; sl < kWave; ++sl) {
-        const int2 meta = *reinterpret_cast<const int2*>(&strip[sl][64]);      // same address in every lane: broadcast
-        if (__builtin_amdgcn_readfirstlane(meta.y) == 0) continue;            // wave-uniform
-        const float v = strip[sl][lane];
-        if (v != 0.0f) atomicAdd(gsrcb + (meta.x + dy * row_stride + in_row), v);
+        const int2 meta = *reinterpret_cast<const int2*>(&strip[sl][Wn::kDwords]);   // same address in every lane
+        if (__builtin_amdgcn_readfirstlane(meta.y) == 0) continue;                  // wave-uniform
+#pragma unroll
+        for (int part = 0; part < Wn::kDwords / kWave; ++part) {
+            const int e = part * kWave + lane;
+            const int dy = e / Wn::kRowDwords, in_row = e % Wn::kRowDwords;
+            const float v = strip[sl][e];
+            if (v != 0.0f) atomicAdd(gsrcb + (meta.x + dy * row_stride + in_row), v);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// accumulate one hypothesis (4 taps x 8 channels) into the lane's window at pixel offset k (0..2)
-__device__ __forceinline__ void window_add(float* __restrict__ mine, int k, const Taps& t, const float (&dwarp)[8]) {
+// accumulate one hypothesis (4 taps x C channels) into the lane's window at pixel offset k (0..2)
+template <int C>
+__device__ __forceinline__ void window_add(float* __restrict__ mine, int k, const Taps& t, const float (&dwarp)[C]) {
     float4* __restrict__ w4 = reinterpret_cast<float4*>(mine);
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap) {
         const float wgt = masked_weight(t, tap);
         if (wgt != 0.0f) {
-            const int q = (((tap >> 1) * 4) + k + (tap & 1)) * 2;
-            float4 a = w4[q], b = w4[q + 1];
-            a.x = fmaf(dwarp[0], wgt, a.x); a.y = fmaf(dwarp[1], wgt, a.y);
-            a.z = fmaf(dwarp[2], wgt, a.z); a.w = fmaf(dwarp[3], wgt, a.w);
-            b.x = fmaf(dwarp[4], wgt, b.x); b.y = fmaf(dwarp[5], wgt, b.y);
-            b.z = fmaf(dwarp[6], wgt, b.z); b.w = fmaf(dwarp[7], wgt, b.w);
-            w4[q] = a;
-            w4[q + 1] = b;
+            const int q = (((tap >> 1) * 4) + k + (tap & 1)) * (C / 4);
+#pragma unroll
+            for (int i = 0; i < C / 4; ++i) {
+                float4 a = w4[q + i];
+                a.x = fmaf(dwarp[4 * i + 0], wgt, a.x);
+                a.y = fmaf(dwarp[4 * i + 1], wgt, a.y);
+                a.z = fmaf(dwarp[4 * i + 2], wgt, a.z);
+                a.w = fmaf(dwarp[4 * i + 3], wgt, a.w);
+                w4[q + i] = a;
+            }
         }
     }
 }
@@ -262,8 +279,8 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
     constexpr int C4 = C / 4;
     constexpr int DL = D / DPL;
     constexpr int PXB = kBlock / DL;
-    constexpr bool kMergeDepths = (C == 8 && DPL > 1);     // window merge of the hypotheses of a pixel (see above)
-    constexpr int kRow = kMergeDepths ? kWinRow : kStageRow;
+    constexpr bool kMergeDepths = (C <= 16 && DPL > 1);    // window merge of the hypotheses of a pixel (see above)
+    constexpr int kRow = kMergeDepths ? Window<C>::kStrip : kStageRow;
     __shared__ __attribute__((aligned(16))) float stage[kBlock / kWave][kWave][kRow];   // wave-private strips
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     if (tile >= dm.ntiles) return;
@@ -363,7 +380,7 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
         [[maybe_unused]] bool have = false;
         [[maybe_unused]] int xb = 0, yb = 0;
         [[maybe_unused]] const int row_stride = dm.Ws * C;
-        if constexpr (kMergeDepths) window_zero(stage[threadIdx.x >> 6][lane]);
+        if constexpr (kMergeDepths) window_zero<C>(stage[threadIdx.x >> 6][lane]);
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
             const float da = what[j] * (dw[j] - sdot) * inv_tc;
@@ -390,10 +407,10 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
                 const bool fits = have && t.iy == yb && k >= 0 && k <= 2;
                 const bool spill = active && have && !fits;
                 if (__any(spill)) {
-                    *reinterpret_cast<int2*>(&mine[64]) = make_int2((yb * dm.Ws + xb) * C, spill ? 1 : 0);
-                    window_flush(strip, lane, gsrcb, row_stride);
+                    *reinterpret_cast<int2*>(&mine[Window<C>::kDwords]) = make_int2((yb * dm.Ws + xb) * C, spill ? 1 : 0);
+                    window_flush<C>(strip, lane, gsrcb, row_stride);
                     if (spill) {
-                        window_zero(mine);
+                        window_zero<C>(mine);
                         have = false;
                     }
                 }
@@ -401,11 +418,13 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
                     if (!have) {
                         // leave room in the direction the later hypotheses move along the epipolar line
                         const bool leftward = taps[DPL - 1].ix < taps[0].ix;
-                        xb = leftward ? (((t.ix + 1) & ~1) - 2) : (t.ix & ~1);
+                        constexpr int A = Window<C>::kAlign;          // 2 (C=8) or 1 (C=16), a power of two
+                        // window = pixels xb..xb+3, xb line-aligned; it must contain t.ix and t.ix+1
+                        xb = leftward ? (((t.ix + 2 + (A - 1)) & ~(A - 1)) - 4) : (t.ix & ~(A - 1));
                         yb = t.iy;
                         have = true;
                     }
-                    window_add(mine, t.ix - xb, t, dwarp);
+                    window_add<C>(mine, t.ix - xb, t, dwarp);
                 }
             } else {
                 dense_scatter<C>(stage[threadIdx.x >> 6], lane, taps[j], dwarp, gsrcb, live);
@@ -413,8 +432,8 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
         }
         if constexpr (kMergeDepths) {
             float (*strip)[kRow] = stage[threadIdx.x >> 6];
-            *reinterpret_cast<int2*>(&strip[lane][64]) = make_int2((yb * dm.Ws + xb) * C, have ? 1 : 0);
-            window_flush(strip, lane, gsrcb, row_stride);
+            *reinterpret_cast<int2*>(&strip[lane][Window<C>::kDwords]) = make_int2((yb * dm.Ws + xb) * C, have ? 1 : 0);
+            window_flush<C>(strip, lane, gsrcb, row_stride);
         }
     }
     float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C);
