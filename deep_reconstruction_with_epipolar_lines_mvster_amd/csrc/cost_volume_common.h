@@ -33,8 +33,11 @@ inline bool shape_instantiated(int C, int G, int D) {
     return cg && (D == 4 || D == 8 || D == 16);
 }
 
-// One lane per pixel (DPL = D) needs enough pixels to give every SIMD of the 256 CUs several waves
-// and few enough channels for the per-lane state to stay in registers; otherwise D lanes per pixel.
+// Lane mapping.  FORWARD: always D lanes per pixel (DPL = 1): the kernel is gather-latency bound (SQ_WAIT_ANY 75 % of
+// wave cycles with one lane per pixel at 132 VGPRs / 3 waves per SIMD); D lanes per pixel need 65 VGPRs, run 7 waves
+// per SIMD and measured 1.55x faster at DTU stages 3-4.  BACKWARD: one lane per pixel (DPL = D) whenever D == 4,
+// C <= 16 and there are enough pixels to fill the chip, because only then can a lane merge the hypotheses of its
+// pixel before the atomic flush (stage 4: 19.0 ms with D lanes per pixel vs 7.8 ms); otherwise D lanes per pixel.
 constexpr long long kMinPixelWaves = 8192;
 constexpr int kMaxWideChannels = 16;
 

@@ -258,12 +258,8 @@ extern "C" int mvster_cost_volume_fwd(const float* ref, const float* const* srcs
     VolumeDims dm{H, W, Hs, Ws, S, 0, attn_temp, (float)sqrt((double)C)};
     const hipStream_t st = as_stream(stream);
     const int cpg = C / G;
-    const bool wide = pick_pixel_per_lane(B, H * W, C, D);
 #define X(CPG_, G_)                                                                                          \
     if (cpg == CPG_ && G == G_) {                                                                            \
-        if constexpr (CPG_ * G_ <= kMaxWideChannels) {                                                       \
-            if (D == 4 && wide) return launch_fwd<CPG_, G_, 4, 4>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st); \
-        }                                                                                                    \
         if (D == 4) return launch_fwd<CPG_, G_, 4, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st);            \
         if (D == 8) return launch_fwd<CPG_, G_, 8, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st);            \
         if (D == 16) return launch_fwd<CPG_, G_, 16, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st);          \
