@@ -29,6 +29,8 @@ PROTOTYPES = {
                                _vp],
     "mvster_depth_regress_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mvster_softmax_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvster_sinkhorn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "mvster_sinkhorn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "mvster_init_range": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_schedule_inverse_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
 }

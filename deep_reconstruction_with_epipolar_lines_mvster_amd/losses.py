@@ -1,0 +1,173 @@
+"""F1 -- drop-ins for the reference's optimal-transport loss.
+
+    sinkhorn       models/mvs4net_utils.py:1164-1210
+    MVS4net_loss   models/MVS4Net.py:195-240
+    Blend_loss     models/MVS4Net.py:243-291
+
+``sinkhorn`` runs as one fused per-pixel HIP kernel (csrc/sinkhorn.hip) instead of ~25 elementwise /
+logsumexp operators per iteration over materialised [B,HW,D,D] tensors; the two ``*_loss`` functions are the
+reference's per-stage bookkeeping around it (same keyword arguments and return tuples).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .hotpath import _need, _on, _stream
+
+__all__ = ["sinkhorn", "MVS4net_loss", "Blend_loss"]
+
+_FUSED_D = (4, 8, 16)
+_MAX_ITERS = 16
+
+
+class _SinkhornPixelLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attn, gt, hypo, mask_u8, iters, eps, continuous, want_tmap):
+        B, D, H, W = attn.shape
+        pix = torch.empty(B, H, W, dtype=torch.float32, device=attn.device)
+        tmap = None
+        if want_tmap:
+            tmap = torch.empty(B, H * W, D, D + (1 if continuous else 0), dtype=torch.float32, device=attn.device)
+        with _on(attn.device):
+            _lib.call("mvster_sinkhorn_fwd", gt.data_ptr(), hypo.data_ptr(), attn.data_ptr(), mask_u8.data_ptr(),
+                      pix.data_ptr(), tmap.data_ptr() if want_tmap else None, B, D, H, W, int(iters), float(eps),
+                      1 if continuous else 0, _stream(attn.device))
+        ctx.save_for_backward(attn, gt, hypo, mask_u8)
+        ctx.cfg = (int(iters), float(eps), bool(continuous))
+        if want_tmap:
+            ctx.mark_non_differentiable(tmap)
+            return pix, tmap
+        return pix, attn.new_empty(0)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gpix, _gtmap):
+        attn, gt, hypo, mask_u8 = ctx.saved_tensors
+        iters, eps, continuous = ctx.cfg
+        B, D, H, W = attn.shape
+        gpix = gpix.contiguous()
+        gattn = torch.empty_like(attn)
+        with _on(attn.device):
+            _lib.call("mvster_sinkhorn_bwd", gt.data_ptr(), hypo.data_ptr(), attn.data_ptr(), mask_u8.data_ptr(),
+                      gpix.data_ptr(), gattn.data_ptr(), B, D, H, W, iters, eps, 1 if continuous else 0,
+                      _stream(attn.device))
+        return gattn, None, None, None, None, None, None, None
+
+
+def _sinkhorn_device_ops(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous):
+    """Shapes the fused kernel does not instantiate (D not in 4/8/16, iters > 16): the same log-domain sweeps as
+    device tensor ops (still no CPU path)."""
+    B, D, H, W = attn_weight.shape
+    dev = attn_weight.device
+    idx = torch.arange(D, device=dev, dtype=torch.float32)
+    cost = (idx[:, None] - idx[None, :]).abs().expand(B, H * W, D, D)
+    if continuous:
+        step = 1 / hypo_depth[:, 2] - 1 / hypo_depth[:, 1]
+        gbin = ((1 / gt_depth - 1 / hypo_depth[:, 0]) / step).masked_fill(~mask, 10.0)
+        last = (gbin.reshape(B, H * W, 1) - idx.view(1, 1, D)).abs()
+        cost = torch.cat([cost, last.unsqueeze(3)], 3)
+        mu = torch.zeros(B, H * W, D + 1, device=dev)
+        mu[:, :, -1] = 1
+    else:
+        gi = (hypo_depth - gt_depth[:, None]).abs().min(1)[1].reshape(B, H * W, 1)
+        mu = torch.zeros(B, H * W, D, device=dev).scatter_(2, gi, 1.0)
+    nu = attn_weight.permute(0, 2, 3, 1).reshape(B, H * W, D)
+    log_mu, log_nu = (mu + 1e-12).log(), (nu + 1e-12).log()
+    u, v = torch.zeros_like(log_nu), torch.zeros_like(log_mu)
+    for _ in range(iters):
+        v = log_mu - torch.logsumexp(cost / eps + u.unsqueeze(3), dim=2)
+        u = log_nu - torch.logsumexp(cost / eps + v.unsqueeze(2), dim=3)
+    tmap = (cost / eps + u.unsqueeze(3) + v.unsqueeze(2)).exp()
+    pix = (tmap * cost).sum((2, 3)).reshape(B, H, W) * mask
+    return pix, tmap
+
+
+def _pixel_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous, want_tmap):
+    attn = _need(attn_weight, "attn_weight", 4)
+    hypo = _need(hypo_depth, "hypo_depth", 4).detach()
+    gt = _need(gt_depth, "gt_depth", 3).detach()
+    if not (isinstance(mask, torch.Tensor) and mask.is_cuda and mask.dtype == torch.bool):
+        raise RuntimeError("mask must be a bool tensor on the HIP device (the reference indexes with it)")
+    B, D, H, W = attn.shape
+    if hypo.shape != attn.shape or tuple(gt.shape) != (B, H, W) or tuple(mask.shape) != (B, H, W):
+        raise RuntimeError("sinkhorn: gt_depth/mask must be [B,H,W] and hypo_depth/attn_weight [B,D,H,W]")
+    if D in _FUSED_D and 0 <= int(iters) <= _MAX_ITERS and (not continuous or D >= 3):
+        mask_u8 = mask.contiguous().view(torch.uint8)
+        pix, tmap = _SinkhornPixelLoss.apply(attn, gt, hypo, mask_u8, int(iters), float(eps), bool(continuous),
+                                             bool(want_tmap))
+        return pix, (tmap if want_tmap else None)
+    return _sinkhorn_device_ops(gt, hypo, attn, mask, int(iters), eps, continuous)
+
+
+def sinkhorn(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continuous=False):
+    """gt_depth [B,H,W], hypo_depth/attn_weight [B,D,H,W], mask [B,H,W] bool -> (T_map [B,HW,D,D(+1)], loss).
+
+    ``loss`` = mean over the masked pixels of sum(T * cost), differentiable w.r.t. ``attn_weight``.  ``T_map`` is
+    returned for signature parity; it carries no gradient and its rows are NaN where ``mask`` is False (the
+    reference computes those rows but never uses them)."""
+    pix, tmap = _pixel_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous, want_tmap=True)
+    return tmap, pix.sum() / mask.sum()
+
+
+def _stage_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous):
+    pix, _ = _pixel_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous, want_tmap=False)
+    return pix.sum() / mask.sum()
+
+
+def _range_miss(hypo_depth, depth_gt, inverse):
+    """Fraction helper of models/MVS4Net.py:220-226: True where no hypothesis lies within one interval of the GT."""
+    if inverse:
+        itv = (1 / hypo_depth[:, 2] - 1 / hypo_depth[:, 1]).abs()
+        near = (1 / hypo_depth - 1 / depth_gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)
+    else:
+        itv = (hypo_depth[:, 2] - hypo_depth[:, 1]).abs()
+        near = (hypo_depth - depth_gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)
+    return near.sum(1) == 0
+
+
+def _stage_items(inputs):
+    return [(k, inputs[k]) for k in inputs.keys() if "stage" in k]
+
+
+def _losses(inputs, depth_gt_ms, mask_ms, kwargs):
+    stage_lw = kwargs.get("stage_lw", [1, 1, 1, 1])
+    l1ot_lw = kwargs.get("l1ot_lw", [0, 1])
+    inverse = kwargs.get("inverse_depth", False)
+    ot_iter = kwargs.get("ot_iter", 3)
+    ot_eps = kwargs.get("ot_eps", 1)
+    ot_continous = kwargs.get("ot_continous", False)
+    mono = kwargs.get("mono", False)
+    dev = mask_ms["stage1"].device
+    total = torch.zeros((), dtype=torch.float32, device=dev)
+    l1s, ots, misses = [], [], []
+    last = None
+    for stage_idx, (key, out) in enumerate(_stage_items(inputs)):
+        mask = mask_ms[key] > 0.5
+        gt = depth_gt_ms[key]
+        if mono and stage_idx != 0:
+            l1 = F.l1_loss(out["mono_depth"][mask], gt[mask], reduction="mean")
+        else:
+            l1 = torch.zeros((), dtype=torch.float32, device=dev)
+        misses.append(_range_miss(out["hypo_depth"], gt, inverse)[mask].float().mean())
+        ot = _stage_loss(gt, out["hypo_depth"], out["attn_weight"], mask, ot_iter, ot_eps, ot_continous)
+        l1s.append(l1)
+        ots.append(ot)
+        total = total + stage_lw[stage_idx] * (l1ot_lw[0] * l1 + l1ot_lw[1] * ot)
+        last = (out["depth"], gt, mask)
+    return total, l1s, ots, misses, last
+
+
+def MVS4net_loss(inputs, depth_gt_ms, mask_ms, **kwargs):
+    """-> (total_loss, stage_l1_loss[], stage_ot_loss[], range_err_ratio[])   (models/MVS4Net.py:195-240)"""
+    total, l1s, ots, misses, _ = _losses(inputs, depth_gt_ms, mask_ms, kwargs)
+    return total, l1s, ots, misses
+
+
+def Blend_loss(inputs, depth_gt_ms, mask_ms, **kwargs):
+    """-> (total_loss, stage_l1_loss[], stage_ot_loss[], range_err_ratio[], epe, err3, err1)  (models/MVS4Net.py:243-291)"""
+    depth_max = kwargs.get("depth_max", 100)
+    depth_min = kwargs.get("depth_min", 1)
+    total, l1s, ots, misses, (pred, gt, mask) = _losses(inputs, depth_gt_ms, mask_ms, kwargs)
+    scale = 128 / (depth_max - depth_min)[:, None, None]
+    abs_err = (pred * scale - gt * scale)[mask].abs()
+    return total, l1s, ots, misses, abs_err.mean(), (abs_err <= 3).float().mean() * 100, (abs_err <= 1).float().mean() * 100

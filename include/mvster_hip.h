@@ -152,6 +152,24 @@ int mvster_init_range(const float *depth_values, int K, float *out, int B, int D
 int mvster_schedule_inverse_range(const float *inv_min, const float *inv_max, float *out, int B, int D,
                                   int Hp, int Wp, int H, int W, mvster_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * F1  Sinkhorn optimal-transport loss between softmax-over-depth `attn` and the ground-truth depth bin,
+ * one fused per-pixel kernel.  pix_loss[b,h,w] = sum_{r,c} T[r,c] * cost[r,c] after `iters` log-domain
+ * sweeps (0 where mask == 0); the stage loss of the reference is mean(pix_loss[mask]).
+ * replaces: models/mvs4net_utils.py:1164-1210 (sinkhorn; `continuous` selects its D x (D+1) variant).
+ *   gt_depth : [B,H,W]   hypo, attn : [B,D,H,W]   mask : [B,H,W] uint8 (0 = ignore)
+ *   pix_loss : [B,H,W]   tmap : [B,H*W,D,D(+1)] transport plan (may be NULL; NaN rows where mask == 0)
+ * Supported: D in {4,8,16}, iters <= 16; otherwise MVSTER_ERR_UNSUPPORTED.
+ */
+int mvster_sinkhorn_fwd(const float *gt_depth, const float *hypo, const float *attn, const uint8_t *mask,
+                        float *pix_loss, float *tmap, int B, int D, int H, int W, int iters, float eps,
+                        int continuous, mvster_stream_t stream);
+
+/* Gradient w.r.t. attn: gattn[b,d,h,w] = gpix[b,h,w] * d pix_loss / d attn (0 where mask == 0). */
+int mvster_sinkhorn_bwd(const float *gt_depth, const float *hypo, const float *attn, const uint8_t *mask,
+                        const float *gpix, float *gattn, int B, int D, int H, int W, int iters, float eps,
+                        int continuous, mvster_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

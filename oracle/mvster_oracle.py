@@ -13,6 +13,8 @@ What it restates (all citations relative to the upstream reference tree):
 * ``init_range``                      models/mvs4net_utils.py:69-77
 * ``init_inverse_range``              models/mvs4net_utils.py:79-85
 * ``schedule_inverse_range``          models/mvs4net_utils.py:87-94
+* ``sinkhorn``                        models/mvs4net_utils.py:1164-1210   
+* ``MVS4net_loss``                    models/MVS4Net.py:195-240
 
 It deliberately uses the same torch operator *sequence* where the operator decides the fp32
 rounding (``torch.inverse``, ``matmul``, the [-1,1] grid round trip through ``F.grid_sample``,
@@ -32,6 +34,7 @@ __all__ = [
     "compose_projection", "relative_pose", "sampling_grid", "homo_warping",
     "fuse_source_views", "regress_depth", "stage_forward",
     "init_range", "init_inverse_range", "schedule_inverse_range",
+    "sinkhorn", "mvs4net_loss",
 ]
 
 
@@ -217,3 +220,76 @@ def schedule_inverse_range(inverse_min_depth, inverse_max_depth, ndepths, H, W):
     inv = inverse_max_depth[:, None] + (inverse_min_depth - inverse_max_depth)[:, None] * frac
     inv = F.interpolate(inv.unsqueeze(1), [ndepths, H, W], mode="trilinear", align_corners=True).squeeze(1)
     return 1.0 / inv
+
+
+# --------------------------------------------------------------------------------------
+# optimal-transport loss
+# --------------------------------------------------------------------------------------
+def sinkhorn(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continuous=False):
+    """Log-domain Sinkhorn between the depth distribution and the GT bin (mvs4net_utils.py:1164-1210).
+
+    Returns (T_map [B,HW,D,D(+1)], loss) with loss = mean over masked pixels of sum(T * cost)."""
+    B, D, H, W = attn_weight.shape
+    dev = gt_depth.device
+    ramp = torch.stack([torch.arange(-i, D - i, 1, dtype=torch.float32, device=dev) for i in range(D)], dim=1).abs()
+    if not continuous:
+        cost = ramp[None, None].repeat(B, H * W, 1, 1)
+        gt_idx = torch.abs(hypo_depth - gt_depth[:, None]).min(1)[1].reshape(B * H * W, 1)
+        target = torch.zeros_like(hypo_depth).permute(0, 2, 3, 1).reshape(B * H * W, D)
+        target.scatter_add_(1, gt_idx, torch.ones([target.shape[0], 1], dtype=target.dtype, device=dev))
+        target = target.reshape(B, H * W, D)
+    else:
+        target = torch.zeros((B, H * W, D + 1), dtype=torch.float32, device=dev)
+        target[:, :, -1] = 1
+        cost = torch.zeros((B, D, D + 1), dtype=torch.float32, device=dev)
+        cost[:, :D, :D] = ramp.unsqueeze(0)
+        cost = cost[:, None, None].repeat(1, H, W, 1, 1)
+        step = 1 / hypo_depth[:, 2] - 1 / hypo_depth[:, 1]
+        gt_bin = (1 / gt_depth - 1 / hypo_depth[:, 0]) / step
+        gt_bin[~mask] = 10
+        cost[..., -1] = torch.stack([(gt_bin - i).abs() for i in range(D)], dim=1).permute(0, 2, 3, 1)
+        cost = cost.reshape(B, H * W, D, D + 1)
+    pred = attn_weight.permute(0, 2, 3, 1).reshape(B, H * W, D)
+    log_mu = (target + 1e-12).log()
+    log_nu = (pred + 1e-12).log()
+    u, v = torch.zeros_like(log_nu), torch.zeros_like(log_mu)
+    for _ in range(iters):
+        v = log_mu - torch.logsumexp(cost / eps + u.unsqueeze(3), dim=2)
+        u = log_nu - torch.logsumexp(cost / eps + v.unsqueeze(2), dim=3)
+    plan = (cost / eps + u.unsqueeze(3) + v.unsqueeze(2)).exp()
+    loss = (plan * cost).reshape(B * H * W, -1)[mask.reshape(-1)].sum(-1).mean()
+    return plan, loss
+
+
+def mvs4net_loss(inputs, depth_gt_ms, mask_ms, **kwargs):
+    """Per-stage OT (+ mono L1) loss (models/MVS4Net.py:195-240) -> (total, l1[], ot[], range_err_ratio[])."""
+    stage_lw = kwargs.get("stage_lw", [1, 1, 1, 1])
+    l1ot_lw = kwargs.get("l1ot_lw", [0, 1])
+    inverse = kwargs.get("inverse_depth", False)
+    iters = kwargs.get("ot_iter", 3)
+    eps = kwargs.get("ot_eps", 1)
+    continuous = kwargs.get("ot_continous", False)
+    mono = kwargs.get("mono", False)
+    total = torch.tensor(0.0, dtype=torch.float32, device=mask_ms["stage1"].device)
+    l1s, ots, misses = [], [], []
+    for n, key in enumerate([k for k in inputs.keys() if "stage" in k]):
+        out = inputs[key]
+        hypo, attn = out["hypo_depth"], out["attn_weight"]
+        mask = mask_ms[key] > 0.5
+        gt = depth_gt_ms[key]
+        if mono and n != 0:
+            l1 = F.l1_loss(out["mono_depth"][mask], gt[mask], reduction="mean")
+        else:
+            l1 = torch.tensor(0.0, dtype=torch.float32, device=total.device)
+        if inverse:
+            itv = (1 / hypo[:, 2] - 1 / hypo[:, 1]).abs()
+            miss = ((1 / hypo - 1 / gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)).sum(1) == 0
+        else:
+            itv = (hypo[:, 2] - hypo[:, 1]).abs()
+            miss = ((hypo - gt.unsqueeze(1)).abs() <= itv.unsqueeze(1)).sum(1) == 0
+        misses.append(miss[mask].float().mean())
+        ot = sinkhorn(gt, hypo, attn, mask, iters=iters, eps=eps, continuous=continuous)[1]
+        l1s.append(l1)
+        ots.append(ot)
+        total = total + stage_lw[n] * (l1ot_lw[0] * l1 + l1ot_lw[1] * ot)
+    return total, l1s, ots, misses

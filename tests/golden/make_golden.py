@@ -13,6 +13,7 @@ reference's outputs / input-gradients for the hot-path functions of SURVEY.md se
   stage_*.npz     stagenet.forward, stub regnets     (models/mvs4net_utils.py:1017-1162)
   range_*.npz     init_range / init_inverse_range / schedule_inverse_range (:69-94)
   ties.npz        arg-max tie behaviour of the post-regnet half (:1126-1130)
+  sinkhorn_*.npz, loss_mvs4net.npz  sinkhorn (:1164-1210) and MVS4net_loss (models/MVS4Net.py:195-240)
   model_e2e_64.npz  MVS4net (models/MVS4Net.py:16-193) seeded construction checksums, eval + train forward, 64x64
 """
 import math
@@ -213,6 +214,49 @@ def make_ties():
              conf=out["photometric_confidence"], inv_min=out["inverse_min_depth"], inv_max=out["inverse_max_depth"])
 
 
+# ------------------------------------------------------------------ sinkhorn / MVS4net_loss
+def make_sinkhorn():
+    from models.mvs4net_utils import sinkhorn
+    from models.MVS4Net import MVS4net_loss
+    g = torch.Generator().manual_seed(501)
+    cases = [("d4_it10", 4, 10, 1.0, False), ("d8_it10", 8, 10, 1.0, False), ("d16_it3", 16, 3, 1.0, False),
+             ("d8_eps01", 8, 5, 0.1, False), ("d4_cont", 4, 10, 1.0, True), ("d8_cont", 8, 3, 1.0, True),
+             ("d5_it4", 5, 4, 1.0, False)]
+    for name, D, iters, eps, cont in cases:
+        B, H, W = 2, 9, 11
+        base = 500 + 300 * torch.rand(B, 1, H, W, generator=g)
+        inv = 1.0 / base + (torch.arange(D).view(1, D, 1, 1) - (D - 1) / 2) * 5e-5
+        hypo = 1.0 / inv                                                     # decreasing depth, like the cascade
+        gt = 1.0 / (1.0 / base[:, 0] + (torch.rand(B, H, W, generator=g) - 0.5) * 5e-5 * (D + 1))
+        mask = torch.rand(B, H, W, generator=g) < 0.7
+        logits = 2 * torch.randn(B, D, H, W, generator=g)
+        attn = torch.softmax(logits, 1).requires_grad_(True)
+        T, loss = sinkhorn(gt, hypo, attn, mask, iters, eps=eps, continuous=cont)
+        loss.backward()
+        save("sinkhorn_" + name, gt=gt, hypo=hypo, attn=attn, mask=mask, T=T, loss=loss, gattn=attn.grad,
+             meta=np.array([D, iters, int(cont)]), eps=np.float32(eps))
+    # MVS4net_loss over a 4-stage output dictionary (inverse depth, mono L1 on stages 2-4)
+    outs, gts, masks, arrays = {}, {}, {}, {}
+    for k, (D, H, W) in enumerate(((8, 6, 8), (8, 12, 16), (4, 24, 32), (4, 48, 64))):
+        key = "stage%d" % (k + 1)
+        base = 500 + 300 * torch.rand(1, 1, H, W, generator=g)
+        hypo = 1.0 / (1.0 / base + (torch.arange(D).view(1, D, 1, 1) - (D - 1) / 2) * 4e-5)
+        attn = torch.softmax(2 * torch.randn(1, D, H, W, generator=g), 1).requires_grad_(True)
+        gts[key] = 1.0 / (1.0 / base[:, 0] + (torch.rand(1, H, W, generator=g) - 0.5) * 3e-4)
+        masks[key] = (torch.rand(1, H, W, generator=g) < 0.7).float()
+        outs[key] = {"depth": torch.gather(hypo, 1, attn.max(1, keepdim=True)[1]).squeeze(1), "hypo_depth": hypo,
+                     "attn_weight": attn, "mono_depth": (gts[key] + torch.randn(1, H, W, generator=g)).requires_grad_(True)}
+        arrays.update({key + "_hypo": hypo, key + "_attn": attn, key + "_gt": gts[key], key + "_mask": masks[key],
+                       key + "_mono": outs[key]["mono_depth"], key + "_depth": outs[key]["depth"]})
+    total, l1s, ots, miss = MVS4net_loss(outs, gts, masks, stage_lw=[1, 1, 1, 1], l1ot_lw=[0.5, 1], inverse_depth=True,
+                                         ot_iter=10, ot_eps=1, ot_continous=False, mono=True)
+    total.backward()
+    arrays.update(total=total, l1=torch.stack(l1s), ot=torch.stack(ots), miss=torch.stack(miss))
+    for key in outs:
+        arrays[key + "_gattn"] = outs[key]["attn_weight"].grad
+    save("loss_mvs4net", **arrays)
+
+
 # ------------------------------------------------------------------ (vi) end-to-end MVS4net
 def model_inputs(B, N, H, W, gen):
     """imgs list, proj_matrices dict stage1..4 (intrinsics scaled 1/8,1/4,1/2,1 like datasets/dataloader_eval.py:281-287),
@@ -296,8 +340,12 @@ if __name__ == "__main__":
     if "--model-only" in sys.argv:
         make_model()
         sys.exit(0)
+    if "--loss-only" in sys.argv:
+        make_sinkhorn()
+        sys.exit(0)
     make_warp()
     make_stages()
     make_ranges()
     make_ties()
+    make_sinkhorn()
     make_model()

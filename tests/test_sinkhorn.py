@@ -1,0 +1,125 @@
+"""F1 sinkhorn / MVS4net_loss: the oracle against the reference's golden vectors (CPU) and the fused HIP kernel
+against both (GPU).  fp32 with 10 log-domain sweeps of exp/log: loss rtol 1e-4, transport plan atol 1e-5,
+gradients rtol 2e-3 of max|g| (the reverse sweep is analytic, torch's is tape-based)."""
+import pytest
+import torch
+
+from oracle import mvster_oracle as orc
+from tests.util import golden, golden_names
+
+STAGES = ("stage1", "stage2", "stage3", "stage4")
+
+
+def case(name):
+    z = golden(name)
+    D, iters, cont = [int(v) for v in z["meta"]]
+    return z, D, iters, bool(cont), float(z["eps"])
+
+
+@pytest.mark.parametrize("name", golden_names("sinkhorn_"))
+def test_oracle_sinkhorn_matches_reference(name):
+    z, D, iters, cont, eps = case(name)
+    attn = z["attn"].clone().requires_grad_(True)
+    T, loss = orc.sinkhorn(z["gt"], z["hypo"], attn, z["mask"], iters, eps=eps, continuous=cont)
+    loss.backward()
+    torch.testing.assert_close(T, z["T"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(loss.detach(), torch.as_tensor(z["loss"]), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(attn.grad, z["gattn"], rtol=1e-4, atol=1e-6 * float(z["gattn"].abs().max()))
+
+
+def loss_inputs(z, device=None, grad=True):
+    outs, gts, masks = {}, {}, {}
+    for k in STAGES:
+        mv_ = lambda t: t.to(device) if device is not None else t.clone()
+        outs[k] = {"depth": mv_(z[k + "_depth"]), "hypo_depth": mv_(z[k + "_hypo"]),
+                   "attn_weight": mv_(z[k + "_attn"]).requires_grad_(grad), "mono_depth": mv_(z[k + "_mono"])}
+        gts[k], masks[k] = mv_(z[k + "_gt"]), mv_(z[k + "_mask"])
+    return outs, gts, masks
+
+
+KW = dict(stage_lw=[1, 1, 1, 1], l1ot_lw=[0.5, 1], inverse_depth=True, ot_iter=10, ot_eps=1, ot_continous=False, mono=True)
+
+
+def test_oracle_mvs4net_loss_matches_reference():
+    z = golden("loss_mvs4net")
+    outs, gts, masks = loss_inputs(z)
+    total, l1s, ots, miss = orc.mvs4net_loss(outs, gts, masks, **KW)
+    total.backward()
+    torch.testing.assert_close(total.detach(), torch.as_tensor(z["total"]), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(torch.stack(ots).detach(), z["ot"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(torch.stack(l1s).detach(), z["l1"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(torch.stack(miss), z["miss"], rtol=0, atol=0)
+    for k in STAGES:
+        torch.testing.assert_close(outs[k]["attn_weight"].grad, z[k + "_gattn"], rtol=1e-4, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", golden_names("sinkhorn_"))
+def test_hip_sinkhorn_matches_reference(name):
+    import deep_reconstruction_with_epipolar_lines_mvster_amd as mv
+    dev = torch.device("cuda:0")
+    z, D, iters, cont, eps = case(name)
+    attn = z["attn"].to(dev).requires_grad_(True)
+    mask = z["mask"].to(dev)
+    T, loss = mv.sinkhorn(z["gt"].to(dev), z["hypo"].to(dev), attn, mask, iters, eps=eps, continuous=cont)
+    loss.backward()
+    assert T.shape == z["T"].shape
+    m = z["mask"].reshape(z["mask"].shape[0], -1)
+    terr = float((T.cpu()[m] - z["T"][m]).abs().max())
+    lerr = abs(float(loss) - float(z["loss"])) / abs(float(z["loss"]))
+    gscale = float(z["gattn"].abs().max())
+    gerr = float((attn.grad.cpu() - z["gattn"]).abs().max()) / gscale
+    print("    [parity] %-22s D=%d iters=%d cont=%d eps=%g: max|T err| %.2e, loss rel err %.2e, grad err / max|g| %.2e"
+          % (name, D, iters, cont, eps, terr, lerr, gerr))
+    assert terr < 1e-5 and lerr < 1e-4 and gerr < 2e-3
+    if D in (4, 8, 16):
+        assert bool(torch.isnan(T.cpu()[~m]).all())            # masked-out rows are flagged, never used
+    assert float(attn.grad.cpu()[~z["mask"][:, None].expand_as(z["attn"])].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_hip_mvs4net_and_blend_loss_match_reference():
+    import deep_reconstruction_with_epipolar_lines_mvster_amd as mv
+    dev = torch.device("cuda:0")
+    z = golden("loss_mvs4net")
+    outs, gts, masks = loss_inputs(z, dev)
+    total, l1s, ots, miss = mv.MVS4net_loss(outs, gts, masks, **KW)
+    total.backward()
+    print("    [parity] MVS4net_loss total %.6f (reference %.6f)" % (float(total), float(z["total"])))
+    torch.testing.assert_close(total.detach().cpu(), torch.as_tensor(z["total"]), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(torch.stack(ots).detach().cpu(), z["ot"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(torch.stack(l1s).detach().cpu(), z["l1"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(torch.stack(miss).cpu(), z["miss"], rtol=0, atol=0)
+    for k in STAGES:
+        g, want = outs[k]["attn_weight"].grad.cpu(), z[k + "_gattn"]
+        assert float((g - want).abs().max()) < 2e-3 * float(want.abs().max())
+    outs2, gts2, masks2 = loss_inputs(z, dev)
+    res = mv.Blend_loss(outs2, gts2, masks2, depth_max=torch.tensor([935.0], device=dev),
+                        depth_min=torch.tensor([425.0], device=dev), **KW)
+    assert len(res) == 7 and abs(float(res[0]) - float(z["total"])) < 1e-4 * abs(float(z["total"]))
+    assert 0.0 <= float(res[5]) <= 100.0 and 0.0 <= float(res[6]) <= float(res[5])
+
+
+@pytest.mark.gpu
+def test_hip_sinkhorn_full_stage4_vs_oracle():
+    """Full DTU stage-4 shape (1184x1600, D=4, 10 sweeps): fused kernel vs the oracle's per-op path."""
+    import deep_reconstruction_with_epipolar_lines_mvster_amd as mv
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    B, D, H, W = 1, 4, 1184, 1600
+    base = 500 + 300 * torch.rand(B, 1, H, W, generator=g)
+    hypo = 1.0 / (1.0 / base + (torch.arange(D).view(1, D, 1, 1) - 1.5) * 3e-6)
+    gt = 1.0 / (1.0 / base[:, 0] + (torch.rand(B, H, W, generator=g) - 0.5) * 2e-5)
+    mask = torch.rand(B, H, W, generator=g) < 0.7
+    attn = torch.softmax(torch.randn(B, D, H, W, generator=g), 1)
+    a_cpu = attn.clone().requires_grad_(True)
+    _, want = orc.sinkhorn(gt, hypo, a_cpu, mask, 10, eps=1, continuous=False)
+    want.backward()
+    a_gpu = attn.to(dev).requires_grad_(True)
+    _, got = mv.sinkhorn(gt.to(dev), hypo.to(dev), a_gpu, mask.to(dev), 10, eps=1, continuous=False)
+    got.backward()
+    lerr = abs(float(got) - float(want)) / abs(float(want))
+    gerr = float((a_gpu.grad.cpu() - a_cpu.grad).abs().max()) / float(a_cpu.grad.abs().max())
+    print("    [parity] stage-4 sinkhorn: loss %.6f vs %.6f (rel %.2e), grad err / max|g| %.2e" % (float(got), float(want), lerr, gerr))
+    assert lerr < 1e-4 and gerr < 2e-3
