@@ -33,6 +33,33 @@ class _ConvBNReLU2d(nn.Module):
         return F.relu(self.bn(self.conv(x)), inplace=True)
 
 
+def _bn_as_2d(bn, y):
+    """BatchNorm3d over [B,C,D,H,W] == batch norm over [B*D,C,H,W]: same per-channel statistics, same parameters."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                        bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
+
+
+def _conv3d_as_2d(conv, x2d, B, D):
+    """A Conv3d whose kernel is (1,k,k) or (3,k,k) with unit depth stride, evaluated as ONE conv2d on depth slices
+    stacked into the batch dimension, x2d = [B*D, Cin, H, W].  (3,k,k): the three depth-shifted copies of the input are
+    concatenated along channels and the weight is folded to [Cout, 3*Cin, k, k].  MIOpen's conv3d weight-gradient path
+    for these shapes is a naive kernel (79 ms per layer at DTU resolution); its 2-D paths are Winograd/implicit GEMM."""
+    w = conv.weight
+    kd = w.shape[2]
+    stride, pad = conv.stride[1:], conv.padding[1:]
+    if kd == 1:
+        return F.conv2d(x2d, w[:, :, 0], conv.bias, stride, pad)
+    assert kd == 3 and conv.stride[0] == 1 and conv.padding[0] == 1
+    C, H, W = x2d.shape[1:]
+    x5 = x2d.view(B, D, C, H, W)
+    pad_slice = x5.new_zeros(B, 1, C, H, W)
+    stacked = torch.cat([torch.cat([pad_slice, x5[:, :-1]], 1), x5, torch.cat([x5[:, 1:], pad_slice], 1)], 2)
+    w2 = w.permute(0, 2, 1, 3, 4).reshape(w.shape[0], 3 * w.shape[1], w.shape[3], w.shape[4])
+    return F.conv2d(stacked.view(B * D, 3 * C, H, W), w2, conv.bias, stride, pad)
+
+
 class _ConvBNReLU3d(nn.Module):
     """conv3d -> BatchNorm3d -> ReLU; attributes ``conv``/``bn`` (models/mvs4net_utils.py:123-130)."""
 
@@ -43,6 +70,9 @@ class _ConvBNReLU3d(nn.Module):
 
     def forward(self, x):
         return F.relu(self.bn(self.conv(x)), inplace=True)
+
+    def forward_slices(self, x2d, B, D):
+        return F.relu(_bn_as_2d(self.bn, _conv3d_as_2d(self.conv, x2d, B, D)), inplace=True)
 
 
 def _pyramid_level(cin, cout, downsample):
@@ -117,8 +147,14 @@ class reg2d(nn.Module):
         self.conv9 = _up3d(4 * b, 2 * b)
         self.conv11 = _up3d(2 * b, b)
         self.prob = nn.Conv3d(8, 1, 1, stride=1, padding=0)      # hard-wired to 8 input channels upstream (:914)
+        # True: evaluate the (1,3,3)/(3,3,3) convolutions as conv2d over depth slices (same parameters, same maths)
+        self.depth_slices_as_batch = True
 
     def forward(self, x):
+        return self.forward_slices(x) if self.depth_slices_as_batch else self.forward_conv3d(x)
+
+    def forward_conv3d(self, x):
+        """The reference's operator sequence (conv3d / ConvTranspose3d / BatchNorm3d), models/mvs4net_utils.py:916-926."""
         e0 = self.conv0(x)
         e1 = self.conv2(self.conv1(e0))
         e2 = self.conv4(self.conv3(e1))
@@ -127,6 +163,28 @@ class reg2d(nn.Module):
         y = e1 + self.conv9(y)
         y = e0 + self.conv11(y)
         return self.prob(y).squeeze(1)
+
+    @staticmethod
+    def _up(seq, x2d):
+        deconv, bn = seq[0], seq[1]
+        y = F.conv_transpose2d(x2d, deconv.weight[:, :, 0], None, stride=deconv.stride[1:], padding=deconv.padding[1:],
+                               output_padding=deconv.output_padding[1:])
+        return F.relu(_bn_as_2d(bn, y), inplace=True)
+
+    def forward_slices(self, x):
+        """Same network, same parameters, with the D depth slices stacked into the batch: every layer is a 2-D
+        convolution on [B*D, C, H, W]."""
+        B, C, D, H, W = x.shape
+        x2d = x.permute(0, 2, 1, 3, 4).reshape(B * D, C, H, W)
+        e0 = self.conv0.forward_slices(x2d, B, D)
+        e1 = self.conv2.forward_slices(self.conv1.forward_slices(e0, B, D), B, D)
+        e2 = self.conv4.forward_slices(self.conv3.forward_slices(e1, B, D), B, D)
+        y = self.conv6.forward_slices(self.conv5.forward_slices(e2, B, D), B, D)
+        y = e2 + self._up(self.conv7, y)
+        y = e1 + self._up(self.conv9, y)
+        y = e0 + self._up(self.conv11, y)
+        y = F.conv2d(y, self.prob.weight[:, :, 0], self.prob.bias)
+        return y.view(B, D, H, W)
 
 
 class mono_depth_decoder(nn.Module):

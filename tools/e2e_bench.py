@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""End-to-end training step of the drop-in MVS4net on one GPU (informational; the headline bench is bench.py):
+FPN4 x N views (MIOpen) -> 4 x [HIP hot path + reg2d (MIOpen)] -> mono head -> MVS4net_loss (HIP sinkhorn, 10 sweeps)
+-> backward -> Adam.  1600x1152 (1184 is illegal for reg2d), N = 5 views, inverse depth, group correlation.
+
+    python tools/e2e_bench.py [--batch 1] [--steps 3] [--height 1152] [--width 1600] [--channels-last]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import deep_reconstruction_with_epipolar_lines_mvster_amd as mv            # noqa: E402
+import bench                                                               # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1152)
+    ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--eval", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, N, H, W = args.batch, args.views, args.height, args.width
+    model = mv.MVS4net(arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8,
+                       stage_splits=[8, 8, 4, 4], depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=True,
+                       group_cor_dim=[8, 8, 4, 4], inverse_depth=True, mono=True, attn_temp=2).to(dev)
+    if args.channels_last:
+        model.to_channels_last(True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    imgs = [torch.rand(B, 3, H, W, device=dev) for _ in range(N)]
+    proj = {}
+    for k, sc in enumerate((8, 4, 2, 1)):
+        proj["stage%d" % (k + 1)] = bench.synth_views(B, N, H // sc, W // sc).to(dev)
+    dv = torch.tensor([[425.0, 935.0]] * B, device=dev)
+    gts = {"stage%d" % (k + 1): 480 + 400 * torch.rand(B, H // sc, W // sc, device=dev) for k, sc in enumerate((8, 4, 2, 1))}
+    masks = {k: (torch.rand_like(v) < 0.7).float() for k, v in gts.items()}
+    kw = dict(stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1, ot_continous=False, mono=True)
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        out = model(imgs, proj, dv)
+        loss = mv.MVS4net_loss(out, gts, masks, **kw)[0]
+        loss.backward()
+        opt.step()
+        return loss
+
+    def eval_step():
+        with torch.no_grad():
+            return model(imgs, proj, dv)["stage4"]["depth"]
+
+    if args.eval:
+        model.eval()
+    step = eval_step if args.eval else train_step
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print("e2e %s step: %dx%d, N=%d, B=%d, channels_last=%s: %.1f ms/step = %.2f ref-views/s, peak mem %.1f GB"
+          % ("eval" if args.eval else "train", W, H, N, B, args.channels_last, dt * 1e3, B / dt,
+             torch.cuda.max_memory_allocated() / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    main()
