@@ -27,8 +27,11 @@ def main():
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--eval", action="store_true")
+    ap.add_argument("--bn", default="miopen", choices=["native", "miopen"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net as _m
+    _m._BN_IMPL = args.bn
     torch.manual_seed(0)
     B, N, H, W = args.batch, args.views, args.height, args.width
     model = mv.MVS4net(arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8,
@@ -68,8 +71,8 @@ def main():
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print("e2e %s step: %dx%d, N=%d, B=%d, channels_last=%s: %.1f ms/step = %.2f ref-views/s, peak mem %.1f GB"
-          % ("eval" if args.eval else "train", W, H, N, B, args.channels_last, dt * 1e3, B / dt,
+    print("e2e %s step (bn=%s): %dx%d, N=%d, B=%d, channels_last=%s: %.1f ms/step = %.2f ref-views/s, peak mem %.1f GB"
+          % ("eval" if args.eval else "train", args.bn, W, H, N, B, args.channels_last, dt * 1e3, B / dt,
              torch.cuda.max_memory_allocated() / 1e9), flush=True)
 
 
