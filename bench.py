@@ -67,11 +67,46 @@ def synth_views(B, N, H, W):
     return mats
 
 
-def make_inputs(B, seed, device):
+def scene_features(B, C, H, W, n_views, gen, device):
+    """Multi-view-consistent synthetic features: a smooth textured surface Z(X,Y) (mm, inside the DTU depth range)
+    seen by the SURVEY 8(d) cameras; channel c of every view samples the same band-limited world texture
+    T_c(X,Y), so the group correlation peaks at the true depth and the cascade produces piecewise-smooth depth
+    maps like real data does (noise features make them spatially random)."""
+    f = 2890.0 * W / 1600.0
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=device),
+                            torch.arange(W, dtype=torch.float32, device=device), indexing="ij")
+    dx, dy = (xs - W / 2.0) / f, (ys - H / 2.0) / f
+
+    def surface(X, Y):
+        return 650.0 + 110.0 * torch.sin(X / 170.0) * torch.cos(Y / 130.0) + 35.0 * torch.sin(X / 41.0 + 1.0) * torch.sin(Y / 53.0)
+
+    mm_per_px = 650.0 / f
+    k = 3
+    period = (5.0 + 20.0 * torch.rand(C, k, generator=gen)) * mm_per_px          # 5..25 px at this stage
+    angle = 6.2832 * torch.rand(C, k, generator=gen)
+    wx = (6.2832 / period * torch.cos(angle)).to(device)
+    wy = (6.2832 / period * torch.sin(angle)).to(device)
+    ph = (6.2832 * torch.rand(C, k, generator=gen)).to(device)
+    feats = []
+    for v in range(n_views):
+        tx, ty = 30.0 * v, -10.0 * v
+        z = torch.full_like(dx, 650.0)
+        for _ in range(8):
+            z = surface(z * dx - tx, z * dy - ty)
+        X, Y = z * dx - tx, z * dy - ty
+        fv = torch.sin(wx.view(C, k, 1, 1) * X + wy.view(C, k, 1, 1) * Y + ph.view(C, k, 1, 1)).sum(1)      # [C,H,W]
+        feats.append(fv.unsqueeze(0).repeat(B, 1, 1, 1).contiguous().requires_grad_(True))
+    return feats
+
+
+def make_inputs(B, seed, device, data="noise"):
     g = torch.Generator().manual_seed(seed)
     stages = []
     for (H, W, C, G, D, scale, itv) in DTU_STAGES:
-        feats = [torch.randn(B, C, H, W, generator=g).to(device).requires_grad_(True) for _ in range(N_SRC + 1)]
+        if data == "scene":
+            feats = scene_features(B, C, H, W, N_SRC + 1, g, device)
+        else:
+            feats = [torch.randn(B, C, H, W, generator=g).to(device).requires_grad_(True) for _ in range(N_SRC + 1)]
         mats = synth_views(B, N_SRC + 1, H, W).to(device)
         lw = torch.randn(B, D, H, W, generator=g).to(device)
         stages.append(dict(feats=feats, mats=mats, lw=lw, H=H, W=W, C=C, G=G, D=D, itv=itv))

@@ -319,6 +319,32 @@ def test_layout_routes_agree(dev, C, G, D, H, W):
         close(results["nhwc_inplace"][1][i], results["nchw"][1][i], 1e-5, 1e-7, "grad feat%d in-place" % i)
 
 
+@pytest.mark.parametrize("stage,coherent", [(3, False), (3, True), (2, False), (2, True), (1, False), (1, True)])
+def test_backward_scatter_paths_agree_full_size(dev, stage, coherent):
+    """The backward has three scatter paths chosen at run time: a workgroup LDS tile (spatially coherent depth), the
+    per-lane hypothesis window (C <= 16, one lane per pixel) and dense per-hypothesis strips.  At full DTU stage
+    shapes, spatially random hypotheses force the per-lane paths, smooth ones the tile path; both must give the
+    gradients of the planar (NCHW) kernel family, which scatters tap by tap."""
+    H, W, C, G, D, scale = DTU_STAGES[stage]
+    feats, mats, hypo = dtu_inputs(H, W, C, D, scale, seed=60 + stage, S=2)
+    if not coherent:
+        g = torch.Generator().manual_seed(5)
+        inv = 1 / 935.0 + (1 / 425.0 - 1 / 935.0) * torch.rand(1, 1, H, W, generator=g)        # random depth per pixel
+        step = (1 / 425.0 - 1 / 935.0) / (64 * 2 ** stage)
+        hypo = (1.0 / (inv + (torch.arange(D).view(1, D, 1, 1) - (D - 1) / 2) * step)).contiguous()
+    pose = mv.stage_poses(mats.to(dev))
+    hy = hypo.to(dev)
+    gvol = torch.randn(1, G, D, H, W, generator=torch.Generator().manual_seed(8)).to(dev)
+    grads = {}
+    for route in ("nchw", "nhwc"):
+        fin = [f.to(dev).requires_grad_(True) for f in feats]
+        vol = mv.fused_cost_volume(fin, pose, hy, G, 2.0, layout=route)
+        vol.backward(gvol)
+        grads[route] = [f.grad for f in fin]
+    for i in range(len(feats)):
+        close(grads["nhwc"][i], grads["nchw"][i], 2e-5, 1e-7, "stage%d %s grad feat%d" % (stage + 1, "smooth" if coherent else "random", i))
+
+
 def test_identical_views_reduce_to_single_view(dev):
     """Size-independent property at the full stage-4 shape: fusing S copies of one source view gives the
     single-view correlation (num/den = S w cor / (1e-8 + S w))."""
@@ -372,6 +398,64 @@ def test_unsupported_shape_uses_composed_hip_route(dev):
     out = net([f.to(dev) for f in feats], mats.to(dev), hypo.to(dev), lambda v: v.sum(1), 0, group_cor=True,
               group_cor_dim=G, split_itv=1.0)
     close(out["attn_weight"], want["attn_weight"], 0.0, 1e-4, "composed route attn")
+
+
+def _stage_vs_oracle(dev, feats, mats, hypo, G, training=False, tol=2e-5):
+    want = orc.stage_forward(feats, mats, hypo, lambda v: 3.0 * v.sum(1), training, group_cor=True, group_cor_dim=G,
+                             split_itv=1.0, inverse_depth=True, mono=False, attn_fuse_d=True, attn_temp=2.0)
+    net = mv.stagenet(inverse_depth=True, attn_temp=2.0).train(training)
+    out = net([f.to(dev) for f in feats], mats.to(dev), hypo.to(dev), lambda v: 3.0 * v.sum(1), 0, group_cor=True,
+              group_cor_dim=G, split_itv=1.0)
+    close(out["attn_weight"], want["attn_weight"], 0.0, tol, "attn")
+    return out, want
+
+
+def test_source_maps_of_another_size_than_the_reference(dev):
+    """The fused kernels normalise with the SOURCE map size (models/mvs4net_utils.py:51-52): src 20x28, ref 16x24."""
+    g = torch.Generator().manual_seed(21)
+    B, C, G, D, H, W, Hs, Ws, N = 2, 16, 4, 4, 16, 24, 20, 28, 3
+    feats = [0.5 * torch.randn(B, C, H, W, generator=g)] + [0.5 * torch.randn(B, C, Hs, Ws, generator=g) for _ in range(N - 1)]
+    mats = synth_views(B, N, H, W, scale=W / 1600.0)
+    hypo = (620 + 30 * torch.arange(D).view(1, D, 1, 1) + 5 * torch.rand(B, 1, H, W, generator=g)).expand(B, D, H, W).contiguous()
+    _stage_vs_oracle(dev, feats, mats, hypo, G)
+
+
+@pytest.mark.parametrize("S", [1, 16, 17])
+def test_view_count_limits(dev, S):
+    """1 source view, the fused kernels' maximum (16) and one more (17: composed HIP route) all match the oracle."""
+    g = torch.Generator().manual_seed(30 + S)
+    B, C, G, D, H, W = 1, 8, 4, 4, 10, 12
+    feats = [0.5 * torch.randn(B, C, H, W, generator=g) for _ in range(S + 1)]
+    mats = synth_views(B, S + 1, H, W, scale=W / 1600.0)
+    mats[:, :, 0, 0, 3] *= 0.2        # keep all 17 views inside the tiny map
+    mats[:, :, 0, 1, 3] *= 0.2
+    hypo = (600 + 40 * torch.arange(D).view(1, D, 1, 1) + torch.rand(B, 1, H, W, generator=g)).expand(B, D, H, W).contiguous()
+    _stage_vs_oracle(dev, feats, mats, hypo, G)
+
+
+def test_all_views_out_of_bounds_and_nan_inputs(dev):
+    """Every tap outside the source maps -> zero correlation, uniform attention, first index, NaN confidence (0/0),
+    exactly like the reference; a NaN feature poisons only its own pixel's samples."""
+    g = torch.Generator().manual_seed(41)
+    B, C, G, D, H, W = 1, 8, 4, 4, 8, 8
+    feats = [torch.randn(B, C, H, W, generator=g) for _ in range(3)]
+    mats = synth_views(B, 3, H, W, scale=W / 1600.0)
+    mats[:, 1:, 0, 0, 3] = 1e6                     # sources a kilometre away: every projection leaves the map
+    hypo = (600 + 40 * torch.arange(D).view(1, D, 1, 1)).expand(B, D, H, W).contiguous().float()
+    out, want = _stage_vs_oracle(dev, feats, mats, hypo, G)
+    assert torch.equal(out["attn_weight"].cpu(), torch.full((B, D, H, W), 0.25))
+    assert torch.isnan(out["photometric_confidence"]).all() and torch.isnan(want["photometric_confidence"]).all()
+    assert torch.equal(out["depth"].cpu(), hypo[:, 0])
+    mats = synth_views(B, 3, H, W, scale=W / 1600.0)
+    feats[1][0, 3, 4, 4] = float("nan")
+    out, want = None, None
+    net = mv.stagenet(inverse_depth=True, attn_temp=2.0).eval()
+    got = net([f.to(dev) for f in feats], mats.to(dev), hypo.to(dev), lambda v: v.sum(1), 0, group_cor=True,
+              group_cor_dim=G, split_itv=1.0)["attn_weight"].cpu()
+    ref = orc.stage_forward(feats, mats, hypo, lambda v: v.sum(1), False, group_cor=True, group_cor_dim=G, split_itv=1.0,
+                            inverse_depth=True, attn_fuse_d=True, attn_temp=2.0)["attn_weight"]
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)) and 0 < int(torch.isnan(ref).sum()) < ref.numel()
+    torch.testing.assert_close(got[~torch.isnan(ref)], ref[~torch.isnan(ref)], rtol=0, atol=1e-5)
 
 
 def test_single_hip_runtime_loaded(dev):

@@ -18,9 +18,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--layout", default="nhwc")
+    ap.add_argument("--data", default="noise", choices=["noise", "scene"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    stages, dv = bench.make_inputs(args.batch, 1234, dev)
+    stages, dv = bench.make_inputs(args.batch, 1234, dev, data=args.data)
     net = mv.stagenet(inverse_depth=True, mono=True, attn_temp=2.0).train()
     prev = None
     for k, st in enumerate(stages):
@@ -55,8 +56,13 @@ def main():
         px = st["H"] * st["W"] * args.batch
         fb = bench.algorithmic_bytes("mvster_cost_volume_fwd", 1, st["C"], st["G"], st["D"], px, 4)
         bb = bench.algorithmic_bytes("mvster_cost_volume_bwd", 1, st["C"], st["G"], st["D"], px, 4)
-        print("stage %d  C%-2d D%d  fwd %7.3f ms (%6.0f GB/s)   bwd %7.3f ms (%6.0f GB/s)" % (
-            k + 1, st["C"], st["D"], tf / args.reps, fb / (tf / args.reps) / 1e6, tb / args.reps, bb / (tb / args.reps) / 1e6), flush=True)
+        if k > 0:
+            d = prev["depth"]
+            rough = float((d[:, :, 1:] - d[:, :, :-1]).abs().mean())
+        else:
+            rough = 0.0
+        print("stage %d  C%-2d D%d  mean|ddepth/dx| %6.2f mm  fwd %7.3f ms (%6.0f GB/s)   bwd %7.3f ms (%6.0f GB/s)" % (
+            k + 1, st["C"], st["D"], rough, tf / args.reps, fb / (tf / args.reps) / 1e6, tb / args.reps, bb / (tb / args.reps) / 1e6), flush=True)
 
 
 if __name__ == "__main__":
