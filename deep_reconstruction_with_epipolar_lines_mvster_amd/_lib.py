@@ -31,6 +31,8 @@ PROTOTYPES = {
     "mvster_softmax_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvster_sinkhorn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "mvster_sinkhorn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "mvster_bn_train_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp],
+    "mvster_bn_train_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvster_init_range": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_schedule_inverse_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
 }

@@ -1,0 +1,245 @@
+// F2/F3 support: training-mode BatchNorm (+ReLU) over NCHW planes, fused into two streaming passes each way.
+//   reference: the BatchNorm2d/3d + ReLU that follows every convolution of FPN4 and reg2d
+//   (models/mvs4net_utils.py:123-130, 230-256, 884-926).  torch routes these to MIOpen's spatial BN, which at the
+//   shapes of this model (8-64 channels, up to 1.8 M pixels per plane, N = B*D slices) runs ~10x below the HBM rate:
+//   42 ms of the 128 ms end-to-end training step on MI355X.  Here:
+//     forward : pass 1 reads x once  -> per-channel shifted sums (double atomics, one pair per workgroup)
+//               pass 2 reads x, writes y = max(0, (x - mean_c)*a_c + beta_c)
+//     backward: pass 1 reads dy, x   -> sum(dy'), sum(dy' * xhat)   (dy' = dy where y > 0)
+//               pass 2 reads dy, x, writes dx = a_c * (dy' - mean(dy') - xhat * mean(dy' * xhat))
+//   Algorithmic bytes: 3T forward, 5T backward for a tensor of T bytes.
+#include <math.h>
+
+#include "mvster_device.h"
+#include "mvster_host.h"
+
+namespace mvster {
+
+constexpr int kBnVec = 4;              // floats per lane per load (16 B)
+constexpr int kBnIters = 8;            // loads per lane per workgroup: 256 * 4 * 8 = 8192 elements per workgroup
+
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* __restrict__ scratch) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m, kWave);
+        b += __shfl_xor(b, m, kWave);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { scratch[2 * wave] = a; scratch[2 * wave + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = scratch[0] + scratch[2] + scratch[4] + scratch[6];
+        b = scratch[1] + scratch[3] + scratch[5] + scratch[7];
+    }
+}
+
+// sums[c] = { sum(x - K_c), sum((x - K_c)^2) } with K_c = x[0, c, 0]: shifting by a sample of the channel keeps
+// E[(x-K)^2] - E[x-K]^2 free of the cancellation the raw moments suffer when |mean| >> std.
+__global__ void __launch_bounds__(kBlock)
+bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int C, int HW) {
+    __shared__ double scratch[8];
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float shift = x[(size_t)c * HW];
+    const float* __restrict__ plane = x + ((size_t)n * C + c) * HW;
+    const int base = blockIdx.x * (kBlock * kBnVec * kBnIters);
+    float s1 = 0.0f, s2 = 0.0f;
+    const bool vec_ok = (HW % kBnVec) == 0;
+#pragma unroll
+    for (int it = 0; it < kBnIters; ++it) {
+        const int i = base + (it * kBlock + threadIdx.x) * kBnVec;
+        if (vec_ok && i + kBnVec <= HW) {
+            const float4 v = *reinterpret_cast<const float4*>(plane + i);
+            const float a = v.x - shift, b = v.y - shift, cc = v.z - shift, d = v.w - shift;
+            s1 += (a + b) + (cc + d);
+            s2 = fmaf(a, a, fmaf(b, b, fmaf(cc, cc, fmaf(d, d, s2))));
+        } else {
+            for (int k = 0; k < kBnVec; ++k)
+                if (i + k < HW) {
+                    const float a = plane[i + k] - shift;
+                    s1 += a;
+                    s2 = fmaf(a, a, s2);
+                }
+        }
+    }
+    double d1 = s1, d2 = s2;
+    block_sum2(d1, d2, scratch);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * c], d1);
+        atomicAdd(&sums[2 * c + 1], d2);
+    }
+}
+
+// per channel: mean, invstd, running statistics (PyTorch semantics: biased variance normalises, unbiased one is
+// tracked), and the affine y = x * a + b that pass 2 applies.
+__global__ void bn_finalize_kernel(const float* __restrict__ x, const double* __restrict__ sums,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ affine, int C, int HW, double count, float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double shift = (double)x[(size_t)c * HW];
+    const double m1 = sums[2 * c] / count, m2 = sums[2 * c + 1] / count;
+    const double mean = shift + m1;
+    double var = m2 - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    if (running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+    const float g = gamma != nullptr ? gamma[c] : 1.0f, b = beta != nullptr ? beta[c] : 0.0f;
+    const float a = g * invstd;
+    affine[2 * c] = a;           // y = (x - mean) * a + beta: subtracting the mean first keeps fp32 exact-ish for |mean| >> std
+    affine[2 * c + 1] = b;
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(kBlock)
+bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ affine, const float* __restrict__ save_mean,
+                float* __restrict__ y, int C, int HW) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float a = affine[2 * c], b = affine[2 * c + 1], mean = save_mean[c];
+    const size_t off = ((size_t)n * C + c) * HW;
+    const int base = blockIdx.x * (kBlock * kBnVec * kBnIters);
+    const bool vec_ok = (HW % kBnVec) == 0;
+#pragma unroll
+    for (int it = 0; it < kBnIters; ++it) {
+        const int i = base + (it * kBlock + threadIdx.x) * kBnVec;
+        if (vec_ok && i + kBnVec <= HW) {
+            float4 v = *reinterpret_cast<const float4*>(x + off + i);
+            v.x = fmaf(v.x - mean, a, b); v.y = fmaf(v.y - mean, a, b); v.z = fmaf(v.z - mean, a, b); v.w = fmaf(v.w - mean, a, b);
+            if (RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+            *reinterpret_cast<float4*>(y + off + i) = v;
+        } else {
+            for (int k = 0; k < kBnVec; ++k)
+                if (i + k < HW) {
+                    const float v = fmaf(x[off + i + k] - mean, a, b);
+                    y[off + i + k] = RELU ? fmaxf(v, 0.0f) : v;
+                }
+        }
+    }
+}
+
+// sums[c] = { sum(dy'), sum(dy' * xhat) }
+template <bool RELU>
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ affine,
+                    const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                    double* __restrict__ sums, int C, int HW) {
+    __shared__ double scratch[8];
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float a = affine[2 * c], b = affine[2 * c + 1], mean = save_mean[c], invstd = save_invstd[c];
+    const size_t off = ((size_t)n * C + c) * HW;
+    const int base = blockIdx.x * (kBlock * kBnVec * kBnIters);
+    float s1 = 0.0f, s2 = 0.0f;
+    auto take = [&](float xv, float g) {
+        if (RELU && !(fmaf(xv - mean, a, b) > 0.0f)) g = 0.0f;
+        s1 += g;
+        s2 = fmaf(g, (xv - mean) * invstd, s2);
+    };
+    const bool vec_ok = (HW % kBnVec) == 0;
+#pragma unroll
+    for (int it = 0; it < kBnIters; ++it) {
+        const int i = base + (it * kBlock + threadIdx.x) * kBnVec;
+        if (vec_ok && i + kBnVec <= HW) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + off + i);
+            const float4 gv = *reinterpret_cast<const float4*>(dy + off + i);
+            take(xv.x, gv.x); take(xv.y, gv.y); take(xv.z, gv.z); take(xv.w, gv.w);
+        } else {
+            for (int k = 0; k < kBnVec; ++k)
+                if (i + k < HW) take(x[off + i + k], dy[off + i + k]);
+        }
+    }
+    double d1 = s1, d2 = s2;
+    block_sum2(d1, d2, scratch);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[2 * c], d1);
+        atomicAdd(&sums[2 * c + 1], d2);
+    }
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ affine,
+                    const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                    const double* __restrict__ sums, float* __restrict__ dx, float* __restrict__ dgamma,
+                    float* __restrict__ dbeta, int C, int HW, double count) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float a = affine[2 * c], b = affine[2 * c + 1], mean = save_mean[c], invstd = save_invstd[c];
+    const float mean_dy = (float)(sums[2 * c] / count), mean_dyx = (float)(sums[2 * c + 1] / count);
+    if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
+        if (dbeta != nullptr) dbeta[c] = (float)sums[2 * c];
+        if (dgamma != nullptr) dgamma[c] = (float)sums[2 * c + 1];
+    }
+    const size_t off = ((size_t)n * C + c) * HW;
+    const int base = blockIdx.x * (kBlock * kBnVec * kBnIters);
+    auto grad = [&](float xv, float g) {
+        if (RELU && !(fmaf(xv - mean, a, b) > 0.0f)) g = 0.0f;
+        return a * (g - mean_dy - (xv - mean) * invstd * mean_dyx);
+    };
+    const bool vec_ok = (HW % kBnVec) == 0;
+#pragma unroll
+    for (int it = 0; it < kBnIters; ++it) {
+        const int i = base + (it * kBlock + threadIdx.x) * kBnVec;
+        if (vec_ok && i + kBnVec <= HW) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + off + i);
+            const float4 gv = *reinterpret_cast<const float4*>(dy + off + i);
+            *reinterpret_cast<float4*>(dx + off + i) = make_float4(grad(xv.x, gv.x), grad(xv.y, gv.y), grad(xv.z, gv.z), grad(xv.w, gv.w));
+        } else {
+            for (int k = 0; k < kBnVec; ++k)
+                if (i + k < HW) dx[off + i + k] = grad(x[off + i + k], dy[off + i + k]);
+        }
+    }
+}
+
+static int check_bn(int N, int C, int HW) {
+    MVSTER_REQUIRE_SHAPE(N > 0 && N <= 65535 && C > 0 && C <= 65535 && HW > 0 && (long long)HW <= kMaxPlane);
+    return MVSTER_OK;
+}
+
+}  // namespace mvster
+
+extern "C" int mvster_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                                   float* save_invstd, float* running_mean, float* running_var, double* sums,
+                                   float* affine, int N, int C, int HW, float momentum, float eps, int relu,
+                                   mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(save_mean); MVSTER_REQUIRE_PTR(save_invstd);
+    MVSTER_REQUIRE_PTR(sums); MVSTER_REQUIRE_PTR(affine);
+    MVSTER_REQUIRE_SHAPE((running_mean == nullptr) == (running_var == nullptr));
+    if (int rc = check_bn(N, C, HW)) return rc;
+    const hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { (void)hipGetLastError(); return MVSTER_ERR_LAUNCH; }
+    dim3 grid(grid_for(HW, kBlock * kBnVec * kBnIters), C, N);
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBlock), 0, st, x, sums, C, HW);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid_for(C, 64)), dim3(64), 0, st, x, sums, gamma, beta, save_mean,
+                       save_invstd, running_mean, running_var, affine, C, HW, (double)N * HW, momentum, eps);
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true>), grid, dim3(kBlock), 0, st, x, affine, save_mean, y, C, HW);
+    else hipLaunchKernelGGL((bn_apply_kernel<false>), grid, dim3(kBlock), 0, st, x, affine, save_mean, y, C, HW);
+    return launch_status();
+}
+
+extern "C" int mvster_bn_train_bwd(const float* dy, const float* x, const float* affine, const float* save_mean,
+                                   const float* save_invstd, float* dx, float* dgamma, float* dbeta, double* sums,
+                                   int N, int C, int HW, int relu, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(dy); MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(affine); MVSTER_REQUIRE_PTR(save_mean);
+    MVSTER_REQUIRE_PTR(save_invstd); MVSTER_REQUIRE_PTR(dx); MVSTER_REQUIRE_PTR(sums);
+    if (int rc = check_bn(N, C, HW)) return rc;
+    const hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { (void)hipGetLastError(); return MVSTER_ERR_LAUNCH; }
+    dim3 grid(grid_for(HW, kBlock * kBnVec * kBnIters), C, N);
+    const double count = (double)N * HW;
+    if (relu) {
+        hipLaunchKernelGGL((bn_bwd_stats_kernel<true>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, C, HW);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, dx, dgamma, dbeta, C, HW, count);
+    } else {
+        hipLaunchKernelGGL((bn_bwd_stats_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, C, HW);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, dx, dgamma, dbeta, C, HW, count);
+    }
+    return launch_status();
+}

@@ -13,7 +13,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .hotpath import stagenet, init_range, init_inverse_range, schedule_inverse_range
+from . import _lib
+from .hotpath import stagenet, init_range, init_inverse_range, schedule_inverse_range, _on, _stream
 
 __all__ = ["MVS4net", "FPN4", "reg2d", "mono_depth_decoder"]
 
@@ -21,20 +22,72 @@ __all__ = ["MVS4net", "FPN4", "reg2d", "mono_depth_decoder"]
 # --------------------------------------------------------------------------------------------------
 # stock PyTorch building blocks (out of scope for HIP kernels; parameter names match the reference)
 # --------------------------------------------------------------------------------------------------
-def _batch_norm(bn, x):
-    """Batch normalisation with the module's parameters/buffers.  Default: F.batch_norm (MIOpen spatial BN on ROCm).
-    MIOpen's BN runs ~10x below the HBM rate at these shapes (8-64 channels, up to 1.8 M pixels per plane: 42 ms of a
-    129 ms training step), but ATen's native kernels (``_BN_IMPL = "native"``) measured slower still on MI355X
-    (142 vs 128 ms per training step, 34 vs 22 ms per eval step); a fused BN+ReLU HIP kernel is the next step here."""
+class _BNReLUTrain(torch.autograd.Function):
+    """Training-mode BatchNorm (+ReLU) as two streaming HIP passes each way (csrc/batchnorm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        dev = x.device
+        y = torch.empty_like(x)
+        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        affine = torch.empty(C, 2, dtype=torch.float32, device=dev)
+        sums = torch.empty(C, 2, dtype=torch.float64, device=dev)
+        opt = lambda t: t.data_ptr() if t is not None else None
+        with _on(dev):
+            _lib.call("mvster_bn_train_fwd", x.data_ptr(), opt(weight), opt(bias), y.data_ptr(), save_mean.data_ptr(),
+                      save_invstd.data_ptr(), opt(running_mean), opt(running_var), sums.data_ptr(), affine.data_ptr(),
+                      N, C, HW, float(momentum), float(eps), 1 if relu else 0, _stream(dev))
+        ctx.save_for_backward(x, affine, save_mean, save_invstd)
+        ctx.cfg = (bool(relu), weight is not None, bias is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, affine, save_mean, save_invstd = ctx.saved_tensors
+        relu, has_w, has_b = ctx.cfg
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        dev = x.device
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        sums = torch.empty(C, 2, dtype=torch.float64, device=dev)
+        with _on(dev):
+            _lib.call("mvster_bn_train_bwd", dy.data_ptr(), x.data_ptr(), affine.data_ptr(), save_mean.data_ptr(),
+                      save_invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), sums.data_ptr(),
+                      N, C, HW, 1 if relu else 0, _stream(dev))
+        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None
+
+
+def _batch_norm(bn, x, relu=False):
+    """Batch normalisation (+ optional ReLU) with the module's parameters/buffers.
+
+    Training mode on a HIP fp32 NCHW-contiguous tensor: our two-pass kernels (``_BN_IMPL = "hip"``, default).
+    MIOpen's spatial BN runs ~10x below the HBM rate at these shapes (8-64 channels, up to 1.8 M pixels per plane:
+    42 ms of a 128 ms training step); ATen's native kernels measured slower still (142 vs 128 ms per step).
+    Eval mode (a per-channel affine) and every other case go through ``F.batch_norm`` (MIOpen on ROCm)."""
     training = bn.training or not bn.track_running_stats
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    if not x.is_cuda or _BN_IMPL == "miopen":
-        return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
-    return torch.native_batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps)[0]
+    fused = (_BN_IMPL == "hip" and training and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+             and bn.momentum is not None and x.dim() >= 3)
+    if fused:
+        rm = bn.running_mean if bn.track_running_stats else None
+        rv = bn.running_var if bn.track_running_stats else None
+        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu)
+    if x.is_cuda and _BN_IMPL == "native":
+        y = torch.native_batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps)[0]
+    else:
+        y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
+    return F.relu(y, inplace=True) if relu else y
 
 
-_BN_IMPL = "miopen"          # "miopen" (F.batch_norm's default routing on ROCm) or "native" (ATen kernels)
+_BN_IMPL = "hip"             # "hip" (csrc/batchnorm.hip for training mode), "miopen" (F.batch_norm) or "native" (ATen)
 
 
 class _ConvBNReLU2d(nn.Module):
@@ -46,12 +99,7 @@ class _ConvBNReLU2d(nn.Module):
         self.bn = nn.BatchNorm2d(cout, momentum=0.1)
 
     def forward(self, x):
-        return F.relu(_batch_norm(self.bn, self.conv(x)), inplace=True)
-
-
-def _bn_as_2d(bn, y):
-    """BatchNorm3d over [B,C,D,H,W] == batch norm over [B*D,C,H,W]: same per-channel statistics, same parameters."""
-    return _batch_norm(bn, y)
+        return _batch_norm(self.bn, self.conv(x), relu=True)
 
 
 def _conv3d_as_2d(conv, x2d, B, D):
@@ -85,7 +133,8 @@ class _ConvBNReLU3d(nn.Module):
         return F.relu(self.bn(self.conv(x)), inplace=True)
 
     def forward_slices(self, x2d, B, D):
-        return F.relu(_bn_as_2d(self.bn, _conv3d_as_2d(self.conv, x2d, B, D)), inplace=True)
+        # BatchNorm3d over [B,C,D,H,W] == batch norm over [B*D,C,H,W]: same per-channel statistics, same parameters
+        return _batch_norm(self.bn, _conv3d_as_2d(self.conv, x2d, B, D), relu=True)
 
 
 def _pyramid_level(cin, cout, downsample):
@@ -182,7 +231,7 @@ class reg2d(nn.Module):
         deconv, bn = seq[0], seq[1]
         y = F.conv_transpose2d(x2d, deconv.weight[:, :, 0], None, stride=deconv.stride[1:], padding=deconv.padding[1:],
                                output_padding=deconv.output_padding[1:])
-        return F.relu(_bn_as_2d(bn, y), inplace=True)
+        return _batch_norm(bn, y, relu=True)
 
     def forward_slices(self, x):
         """Same network, same parameters, with the D depth slices stacked into the batch: every layer is a 2-D

@@ -170,6 +170,23 @@ int mvster_sinkhorn_bwd(const float *gt_depth, const float *hypo, const float *a
                         const float *gpix, float *gattn, int B, int D, int H, int W, int iters, float eps,
                         int continuous, mvster_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * F2/F3  training-mode BatchNorm (+ optional fused ReLU) over [N,C,HW] planes (NCHW, or [B*D,C,H,W] depth slices).
+ * replaces: the BatchNorm2d/3d + ReLU after every convolution of FPN4 / reg2d / the mono head
+ * (models/mvs4net_utils.py:123-130,230-256) when the module is in training mode.
+ *   forward : y = relu?(gamma * (x - mean) / sqrt(var + eps) + beta), batch statistics over N*HW per channel
+ *             (biased variance), running_mean/var updated with `momentum` (unbiased variance), PyTorch semantics.
+ *             save_mean, save_invstd : [C]; affine : [C,2] (a_c, beta_c with y = (x-mean_c)*a_c + beta_c); sums : [C,2] double scratch.
+ *             gamma/beta/running_* may be NULL.
+ *   backward: dx, dgamma, dbeta from dy and the SAME x, affine, save_mean, save_invstd (the ReLU mask is recomputed).
+ */
+int mvster_bn_train_fwd(const float *x, const float *gamma, const float *beta, float *y, float *save_mean,
+                        float *save_invstd, float *running_mean, float *running_var, double *sums, float *affine,
+                        int N, int C, int HW, float momentum, float eps, int relu, mvster_stream_t stream);
+int mvster_bn_train_bwd(const float *dy, const float *x, const float *affine, const float *save_mean,
+                        const float *save_invstd, float *dx, float *dgamma, float *dbeta, double *sums, int N, int C,
+                        int HW, int relu, mvster_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,56 @@
+"""GPU: fused training-mode BatchNorm(+ReLU) kernels (csrc/batchnorm.hip) against torch's batch norm evaluated in
+float64 on the CPU: outputs, running statistics, input / weight / bias gradients."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,relu,mean_shift", [((2, 8, 37, 53), True, 0.0), ((4, 16, 64, 80), True, 5.0),
+                                                  ((8, 32, 30, 40), False, -3.0), ((1, 64, 18, 25), True, 100.0),
+                                                  ((4, 8, 296, 400), True, 0.5), ((3, 5, 7), True, 0.0)])
+def test_fused_bn_relu_matches_float64_batch_norm(shape, relu, mean_shift):
+    from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net as m
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    x = (torch.randn(shape, generator=g) * (0.5 + torch.rand(1, C, *([1] * (len(shape) - 2)), generator=g)) + mean_shift)
+    Mod = nn.BatchNorm2d if len(shape) == 4 else nn.BatchNorm1d
+    bn = Mod(C)
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(C, generator=g))
+        bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(0.5 + torch.rand(C, generator=g))
+    ref = Mod(C).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    w = torch.randn(shape, generator=g)
+
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr = F.relu(yr) if relu else yr
+    (yr * w.double()).sum().backward()
+
+    bn = bn.to(dev).train()
+    m._BN_IMPL = "hip"
+    xg = x.to(dev).requires_grad_(True)
+    yg = m._batch_norm(bn, xg, relu=relu)
+    (yg * w.to(dev)).sum().backward()
+
+    def err(a, b):
+        return float((a.detach().cpu().double() - b.detach()).abs().max()) / (float(b.detach().abs().max()) + 1e-30)
+
+    e = dict(y=err(yg, yr), dx=err(xg.grad, xr.grad), dw=err(bn.weight.grad, ref.weight.grad), db=err(bn.bias.grad, ref.bias.grad),
+             rm=err(bn.running_mean, ref.running_mean), rv=err(bn.running_var, ref.running_var))
+    print("    [parity] bn%s relu=%d shift=%g: " % (tuple(shape), relu, mean_shift) + "  ".join("%s %.1e" % kv for kv in e.items()))
+    assert e["y"] < 2e-6 and e["rm"] < 1e-6 and e["rv"] < 1e-5
+    assert e["dx"] < 2e-5 and e["dw"] < 2e-5 and e["db"] < 2e-5
+    assert int(bn.num_batches_tracked) == 1
+    # eval mode goes through F.batch_norm and uses the running statistics the fused kernel just updated
+    bn.eval()
+    ye = m._batch_norm(bn, x.to(dev), relu=relu)
+    ref.eval()
+    yre = F.relu(ref(x.double())) if relu else ref(x.double())
+    assert err(ye, yre) < 5e-6

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--eval", action="store_true")
-    ap.add_argument("--bn", default="miopen", choices=["native", "miopen"])
+    ap.add_argument("--bn", default="hip", choices=["hip", "native", "miopen"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net as _m
