@@ -458,6 +458,45 @@ def test_all_views_out_of_bounds_and_nan_inputs(dev):
     torch.testing.assert_close(got[~torch.isnan(ref)], ref[~torch.isnan(ref)], rtol=0, atol=1e-5)
 
 
+def test_concurrent_host_threads_on_private_streams(dev):
+    """nn.DataParallel drives the reference's model from one Python thread per GPU (train_mvs4.py:574): the ABI must be
+    re-entrant and launch on the caller's current stream.  Two threads, each on its own stream, must reproduce the
+    sequential result bit for bit."""
+    import threading
+    g = torch.Generator().manual_seed(77)
+    B, C, G, D, H, W, N = 1, 16, 4, 4, 96, 128, 4
+    cases = []
+    for k in range(2):
+        feats = [torch.randn(B, C, H, W, generator=g).to(dev) for _ in range(N)]
+        mats = synth_views(B, N, H, W, scale=W / 1600.0).to(dev)
+        hypo = (600 + 30 * torch.arange(D).view(1, D, 1, 1) + 10 * torch.rand(B, 1, H, W, generator=g)).expand(B, D, H, W).contiguous().to(dev)
+        cases.append((feats, mats, hypo))
+    net = mv.stagenet(inverse_depth=True, attn_temp=2.0).eval()
+
+    def run(case):
+        feats, mats, hypo = case
+        out = net(feats, mats, hypo, lambda v: 5.0 * v.sum(1), 0, group_cor=True, group_cor_dim=G, split_itv=1.0)
+        return out["attn_weight"], out["depth"]
+
+    want = [run(c) for c in cases]
+    torch.cuda.synchronize()
+    got = [None, None]
+
+    def worker(i):
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            for _ in range(5):
+                res = run(cases[i])
+        stream.synchronize()
+        got[i] = res
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for i in range(2):
+        assert torch.equal(got[i][0], want[i][0]) and torch.equal(got[i][1], want[i][1])
+
+
 def test_single_hip_runtime_loaded(dev):
     """Our library must share torch's HIP runtime (one libamdhip64 mapped), otherwise streams are foreign."""
     maps = open("/proc/self/maps").read()
