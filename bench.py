@@ -333,6 +333,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="reference views per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--data", default="noise", choices=["noise", "scene"],
+                    help="noise: N(0,1) features (SURVEY 8d; spatially random depth, worst case for gather/scatter); "
+                         "scene: multi-view-consistent textured surface (smooth depth like real data)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank REHEARSAL on a single GPU: every rank uses cuda:0 and the exchange runs over gloo "
+                         "(RCCL refuses two ranks on one device); exercises the N>1 control path, not a measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -340,15 +346,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo", init_method="env://")
+        else:
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
     _lib.load()
 
     B = args.batch
-    stages, dv = make_inputs(B, seed=rank_seed(rank), device=device)
+    stages, dv = make_inputs(B, seed=rank_seed(rank), device=device, data=args.data)
     net = mv.stagenet(inverse_depth=True, mono=True, attn_fuse_d=True, attn_temp=ATTN_TEMP).train()
     grad_vec = torch.zeros(DDP_GRAD_ELEMS, device=device) if world > 1 else None
     timer = LaunchTimer()
@@ -374,7 +385,7 @@ def main():
                     "avg_ms": round(r["avg_ms"], 4), "launches": r["launches"],
                     "GBps": round(r["algorithmic_bytes"] / (r["avg_ms"] * 1e-3) / 1e9, 1)} for r in rows[:8]]
         symbol = kernel_symbol(dom["entry"], dom["B"], dom["C"], dom["G"], dom["D"], dom["HW"])
-        traffic, traffic_src, pmc = pmc_traffic(symbol) if B == 4 else (None, None, None)
+        traffic, traffic_src, pmc = pmc_traffic(symbol) if (B == 4 and args.data == "noise") else (None, None, None)
         out = {
             "metric": "reference-views/sec (fwd+bwd), DTU 1600x1184 N=5 D=(8,8,4,4)",
             "value": whole_job_rate(world, B, args.steps, elapsed),
@@ -387,7 +398,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if args.data == "noise" else "synthetic (multi-view-consistent scene features)",
             "config": {"workload": "MVSTER cost-volume hot path fwd+bwd (stub regnet), DTU 1600x1184 stage shapes "
                                    "148x200/296x400/592x800/1184x1600, 1 ref + 4 src views, D=(8,8,4,4), G=(8,8,4,4), "
                                    "C=(64,32,16,8), inverse depth, attn_temp 2",
