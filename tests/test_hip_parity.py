@@ -458,6 +458,50 @@ def test_all_views_out_of_bounds_and_nan_inputs(dev):
     torch.testing.assert_close(got[~torch.isnan(ref)], ref[~torch.isnan(ref)], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_shapes_forward_backward_vs_oracle(dev, seed):
+    """Seeded sweep over (C, G, D, S, B, H, W, camera yaw, train/eval, ragged source size): whole stagenet forward and
+    the gradients of all feature maps against the oracle.  Covers every fused instantiation family and, for the
+    shapes the fused kernels do not instantiate, the composed HIP route."""
+    import random
+    rnd = random.Random(1000 + seed)
+    C, G = rnd.choice([(8, 4), (8, 8), (16, 4), (16, 8), (32, 4), (32, 8), (64, 4), (64, 8), (24, 8), (12, 4)])
+    D = rnd.choice([4, 8, 16, 6])
+    S = rnd.choice([1, 2, 3, 5])
+    B = rnd.choice([1, 2, 3])
+    H, W = rnd.randrange(9, 40), rnd.randrange(9, 48)
+    ragged = rnd.random() < 0.3
+    Hs, Ws = (H + rnd.randrange(-3, 4), W + rnd.randrange(-3, 4)) if ragged else (H, W)
+    training = rnd.random() < 0.5
+    g = torch.Generator().manual_seed(seed)
+    feats = [0.7 * torch.randn(B, C, H, W, generator=g)] + [0.7 * torch.randn(B, C, Hs, Ws, generator=g) for _ in range(S)]
+    mats = synth_views(B, S + 1, H, W, scale=W / 1600.0, yaw_deg=rnd.choice([0.0, 0.5, 2.0]))
+    mats[:, :, 0, :2, 3] *= rnd.choice([0.1, 0.3, 1.0])
+    base = 1.0 / (520 + 300 * torch.rand(B, 1, H, W, generator=g))
+    hypo = (1.0 / (base + (torch.arange(D).view(1, D, 1, 1) - (D - 1) / 2) * rnd.choice([1e-5, 6e-5, 2e-4]))).contiguous()
+    cw = 4.0 * (0.5 + torch.rand(G, generator=g))
+    lw = torch.randn(B, D, H, W, generator=g)
+
+    def regnet_for(device):
+        w = cw.to(device).view(1, -1, 1, 1, 1)
+        return lambda v: (v * w).sum(1)
+
+    cf = [f.clone().requires_grad_(True) for f in feats]
+    want = orc.stage_forward(cf, mats, hypo, regnet_for("cpu"), training, group_cor=True, group_cor_dim=G, split_itv=0.5,
+                             inverse_depth=True, mono=False, attn_fuse_d=True, attn_temp=2.0)
+    (want["attn_weight"] * lw).sum().backward()
+    gf = [f.to(dev).requires_grad_(True) for f in feats]
+    net = mv.stagenet(inverse_depth=True, attn_temp=2.0).train(training)
+    out = net(gf, mats.to(dev), hypo.to(dev), regnet_for(dev), 0, group_cor=True, group_cor_dim=G, split_itv=0.5)
+    (out["attn_weight"] * lw.to(dev)).sum().backward()
+    tag = "C%d G%d D%d S%d B%d %dx%d src %dx%d %s" % (C, G, D, S, B, H, W, Hs, Ws, "train" if training else "eval")
+    close(out["attn_weight"], want["attn_weight"], 0.0, 5e-5, tag + " attn")
+    flips = int((out["attn_weight"].max(1)[1].cpu() != want["argmax_index"]).sum())
+    assert flips <= max(1, B * H * W // 500), "%s: %d arg-max flips" % (tag, flips)
+    for i in range(S + 1):
+        close(gf[i].grad, cf[i].grad, 2e-4, 1e-7, tag + " grad feat%d" % i)
+
+
 def test_concurrent_host_threads_on_private_streams(dev):
     """nn.DataParallel drives the reference's model from one Python thread per GPU (train_mvs4.py:574): the ABI must be
     re-entrant and launch on the caller's current stream.  Two threads, each on its own stream, must reproduce the
