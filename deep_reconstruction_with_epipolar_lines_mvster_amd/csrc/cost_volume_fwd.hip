@@ -1,5 +1,5 @@
-// A2/A3  fused homography warp + group-wise correlation + softmax-over-depth view weight + fusion
-// over source views, forward and backward.   reference: models/mvs4net_utils.py:1036-1102 (+ autograd).
+// A2  fused homography warp + group-wise correlation + softmax-over-depth view weight + fusion over source views,
+// forward (backward: cost_volume_bwd.hip).   reference: models/mvs4net_utils.py:1036-1102 (+ autograd).
 //
 // Work decomposition (gfx950, wave64): a workgroup of 256 lanes owns 256/DL consecutive reference
 // pixels (row-major), DL = D/DPL lanes per pixel, each lane carrying DPL depth hypotheses.  Lanes of
@@ -8,11 +8,13 @@
 // denominator) lives in registers for the whole source-view loop.  The [B,C,D,H,W] warped volume of
 // the reference is never written: HBM traffic is one read of every feature map, the hypotheses,
 // and one write of the fused [B,G,D,H,W] volume.
-//   DPL = D  (one lane = one pixel): fully coalesced along the row, used when there are enough
-//             pixels to fill 256 CUs (D = 4 stages at full resolution);
-//   DPL = 1  (D lanes per pixel): D x more lanes, used for the small coarse stages.
-// Feature maps are NCHW planes: for a fixed (channel, depth) the 4 bilinear taps of consecutive
-// pixels fall on consecutive addresses of at most two source rows.
+//   DPL = 1  (D lanes per pixel): what the forward always uses -- it is gather-latency bound and this mapping runs
+//             7 waves per SIMD at 65 VGPRs (1.55x faster than one lane per pixel at the DTU stage-3/4 shapes);
+//   DPL = D  (one lane = one pixel): used by the backward at D = 4 (cost_volume_bwd.hip), where a lane must see all
+//             hypotheses of its pixel to merge them before the atomic flush.
+// Two kernel families: the planar one right below reads NCHW feature planes (for a fixed (channel, depth) the taps of
+// consecutive pixels fall on consecutive addresses of at most two source rows -- fine for coherent depth); the
+// channels-last one further down is what the training / inference path uses.
 #include "cost_volume_common.h"
 
 namespace mvster {
