@@ -3,12 +3,14 @@
   (2) the CPU oracle (oracle/mvster_oracle.py) on the same seeded inputs, up to the full DTU stage shapes.
 
 Tolerances (fp32 path; BASELINE.json north_star: 1e-3 abs on depth maps, bit-exact arg-max indices):
-  * fused volume / warped features: |err| <= 2e-4 * max|ref| + 1e-5.  The reference evaluates the homography with
-    an fp32 LAPACK inverse, ours in fp64; sample positions differ by ~1e-4 px (measured), and
-    white-noise features turn that into ~1e-4 relative error of a bilinear sample.
+  * fused volume at the full DTU / plumbing / high-res stage shapes vs the oracle: |err| <= 2e-5 * max|ref| + 1e-6
+    (measured <= 7e-7 * max|ref|); attention through a stub regnet <= 5e-5 abs (measured <= 1.5e-6).
+  * golden fixtures from the reference: |err| <= 2e-4 * max|ref| + 1e-5 + 3x the reference's OWN fp32 distance from
+    the float64 result (the reference inverts the homography in fp32 LAPACK, we in fp64; on the ill-conditioned
+    fixture it is 4.8e-3 off, we are 8.8e-5 off), and the HIP result must be at least as close to float64 as that.
   * arg-max indices and gathered depths: bit-exact given identical logits (test_regress_*);
-    end-to-end through a stub regnet they are exact on every fixture.
-  * gradients: fp32 atomics, order varies: |err| <= 1e-3 * max|ref|.
+    end-to-end through a stub regnet they are exact on every fixture and at every full-size stage shape.
+  * gradients: fp32 atomics, summation order varies: |err| <= 1e-4 * max|ref| at full size (measured <= 1.1e-6).
 """
 import numpy as np
 import pytest
@@ -267,8 +269,8 @@ def test_dtu_stage_forward_backward_vs_oracle(dev, stage):
 
     net = mv.stagenet(inverse_depth=True, mono=False, attn_fuse_d=True, attn_temp=2.0).train()
     out = net(gpu_feats, mats.to(dev), hypo.to(dev), regnet, stage, group_cor=True, group_cor_dim=G, split_itv=0.5)
-    close(seen["vol"], want_vol, 2e-4, 1e-5, "stage%d volume" % (stage + 1))
-    close(out["attn_weight"], want["attn_weight"], 0.0, 2e-3, "stage%d attn_weight" % (stage + 1))
+    close(seen["vol"], want_vol, 2e-5, 1e-6, "stage%d volume" % (stage + 1))
+    close(out["attn_weight"], want["attn_weight"], 0.0, 5e-5, "stage%d attn_weight" % (stage + 1))
     idx = out["attn_weight"].max(1)[1].cpu()
     match = float((idx == want["argmax_index"]).float().mean())
     print("    [parity] stage%d arg-max index match rate through the stub regnet: %.6f" % (stage + 1, match))
@@ -279,7 +281,7 @@ def test_dtu_stage_forward_backward_vs_oracle(dev, stage):
     assert torch.equal(out["depth"].cpu()[same], want["depth"][same])
     (out["attn_weight"] * lw.to(dev)).sum().backward()
     for i in range(len(feats)):
-        close(gpu_feats[i].grad, cpu_feats[i].grad, 2e-3, 1e-7, "stage%d grad feat%d" % (stage + 1, i))
+        close(gpu_feats[i].grad, cpu_feats[i].grad, 1e-4, 1e-7, "stage%d grad feat%d" % (stage + 1, i))
 
 
 @pytest.mark.parametrize("C,G,D,H,W", [(8, 4, 4, 33, 47), (16, 4, 4, 20, 31), (32, 8, 8, 17, 23), (64, 8, 8, 9, 14),
@@ -398,6 +400,37 @@ def test_unsupported_shape_uses_composed_hip_route(dev):
     out = net([f.to(dev) for f in feats], mats.to(dev), hypo.to(dev), lambda v: v.sum(1), 0, group_cor=True,
               group_cor_dim=G, split_itv=1.0)
     close(out["attn_weight"], want["attn_weight"], 0.0, 1e-4, "composed route attn")
+
+
+# BASELINE.json configs[0] ("plumbing": 640x512, 3 src views, D = 4,4,4,4) and configs[4] ("high-res": 2048x1536, 9 src
+# views, D = 16,8,8,4) stage shapes: parity cases, not bench lines.
+OTHER_CONFIG_STAGES = [
+    ("plumbing-s1", 64, 80, 64, 8, 4, 3, True), ("plumbing-s2", 128, 160, 32, 8, 4, 3, True),
+    ("plumbing-s3", 256, 320, 16, 4, 4, 3, True), ("plumbing-s4", 512, 640, 8, 4, 4, 3, True),
+    ("hires-s1", 192, 256, 64, 8, 16, 9, True), ("hires-s2", 384, 512, 32, 8, 8, 9, True),
+    ("hires-s3", 768, 1024, 16, 4, 8, 9, False), ("hires-s4", 1536, 2048, 8, 4, 4, 9, False),
+]
+
+
+@pytest.mark.parametrize("name,H,W,C,G,D,S,with_backward", OTHER_CONFIG_STAGES, ids=[c[0] for c in OTHER_CONFIG_STAGES])
+def test_other_baseline_config_stage_shapes(dev, name, H, W, C, G, D, S, with_backward):
+    feats, mats, hypo = dtu_inputs(H, W, C, D, W / 2048.0 if name.startswith("hires") else W / 640.0, seed=len(name) + H, S=S)
+    mats[:, :, 0, :2, 3] *= 0.5                                   # keep most of the 9 views inside the image
+    want_vol = orc.fuse_source_views(feats, mats, hypo, True, G, 2.0, True)
+    gf = [f.to(dev).requires_grad_(with_backward) for f in feats]
+    vol = mv.fused_cost_volume(gf, mv.stage_poses(mats.to(dev)), hypo.to(dev), G, 2.0)
+    close(vol, want_vol, 2e-5, 1e-6, name + " volume")
+    logits = 6.0 * want_vol.sum(1)
+    want = orc.regress_depth(logits, hypo, training=False, inverse_depth=True, split_itv=0.5)
+    got = mv.depth_regress(logits.to(dev), hypo.to(dev), training=False, inverse_depth=True, split_itv=0.5)
+    assert torch.equal(got["index"].cpu().long(), want["argmax_index"]) and torch.equal(got["depth"].cpu(), want["depth"])
+    if with_backward:
+        cf = [f.clone().requires_grad_(True) for f in feats]
+        gw = torch.randn(want_vol.shape, generator=torch.Generator().manual_seed(2))
+        (orc.fuse_source_views(cf, mats, hypo, True, G, 2.0, True) * gw).sum().backward()
+        (vol * gw.to(dev)).sum().backward()
+        for i in (0, 1, S):
+            close(gf[i].grad, cf[i].grad, 1e-4, 1e-7, name + " grad feat%d" % i)
 
 
 def _stage_vs_oracle(dev, feats, mats, hypo, G, training=False, tol=2e-5):
