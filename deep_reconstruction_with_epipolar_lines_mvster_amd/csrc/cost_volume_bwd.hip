@@ -268,6 +268,32 @@ __device__ __forceinline__ void window_add(float* __restrict__ mine, int k, cons
     }
 }
 
+
+// flush of the two-lanes-per-pixel kernel (C = 16): source lanes 2k and 2k+1 hold channels 0-7 / 8-15 of the same
+// window; one wave-instruction adds one window row of the pair = 4 pixels x 16 channels = 256 contiguous bytes.
+template <int C>
+__device__ __forceinline__ void split_window_flush(float (*strip)[Window<8>::kStrip], int lane, float* __restrict__ gsrcb,
+                                                   int row_stride) {
+    static_assert(C == 16, "split flush: two 8-channel halves per pixel");
+    using Wn = Window<8>;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int px = lane >> 4, half = (lane >> 3) & 1, c = lane & 7;
+    for (int k = 0; k < kWave / 2; ++k) {
+        const int2 meta = *reinterpret_cast<const int2*>(&strip[2 * k][Wn::kDwords]);   // same address in every lane
+        if (__builtin_amdgcn_readfirstlane(meta.y) == 0) continue;                     // wave-uniform
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            const float v = strip[2 * k + half][row * Wn::kRowDwords + px * 8 + c];
+            if (v != 0.0f) atomicAdd(gsrcb + (meta.x + row * row_stride + (lane & 63)), v);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------------------- backward, channels-last features
 template <int C, int G, int D, int DPL>
 __global__ void __launch_bounds__(kBlock)
@@ -448,6 +474,180 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
     }
 }
 
+
+// ------------------------------------------------------------------------------- backward, C = 16, two lanes per pixel
+// With 16 channels the one-lane-per-pixel kernel above needs a 128-dword window per lane (135 KB of LDS per workgroup)
+// and 256 VGPRs: one wave per SIMD, and it falls 35 % short of the atomic request ceiling.  Here a pixel is shared by
+// HS = 2 adjacent lanes, each owning 8 of the 16 channels (whole correlation groups): the per-lane window is the
+// C = 8 one (64 dwords), the workgroup is back to 70 KB of LDS / two workgroups per CU, and only the sums over ALL
+// groups (softmax input, dw) cross the lane pair (one xor-1 shuffle each).  The flush walks lane PAIRS so that one
+// wave-instruction still covers whole 64-byte pixels: 4 pixels x 16 channels = 256 contiguous bytes per row.
+template <int C, int G, int D>
+__global__ void __launch_bounds__(kBlock, 2)      // 70 KB of LDS admits two workgroups per CU: keep the registers there too
+cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* __restrict__ vol,
+                                  const float* __restrict__ wsum, const float* __restrict__ ref, SrcPtrs srcs,
+                                  const float* __restrict__ pose, const float* __restrict__ hypo,
+                                  float* __restrict__ gref, GradPtrs gsrcs, VolumeDims dm) {
+    constexpr int HS = 2;                 // lanes per pixel
+    constexpr int CL = C / HS;            // channels per lane (8)
+    constexpr int CPG = C / G;
+    constexpr int GL = G / HS;            // correlation groups per lane
+    constexpr int CL4 = CL / 4;
+    static_assert(CL == 8 && CL % CPG == 0 && GL >= 1, "split kernel: 16 channels, whole groups per lane");
+    constexpr int PXB = kBlock / HS;
+    using Wn = Window<CL>;
+    __shared__ __attribute__((aligned(16))) float stage[kBlock / kWave][kWave][Wn::kStrip];
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    if (tile >= dm.ntiles) return;
+    const int b = blockIdx.y;
+    const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
+    const int h = threadIdx.x % HS, pl = threadIdx.x / HS;
+    const int praw = tile * PXB + pl;
+    const bool live = praw < HW;
+    const int p = live ? praw : HW - 1;
+    const int y = p / dm.W, x = p - y * dm.W;
+    const float fx = (float)x, fy = (float)y;
+    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+    const float inv_tc = 1.0f / (dm.temp * dm.sqrt_c);
+    const int lane = threadIdx.x & 63;
+    float (*strip)[Wn::kStrip] = stage[threadIdx.x >> 6];
+    float* __restrict__ mine = strip[lane];
+    const int row_stride = dm.Ws * C;
+
+    const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C + h * CL);
+    float hyp[D], gd[GL][D], godot[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        hyp[d] = hypo[((size_t)b * D + d) * HW + p];
+        const float rden = 1.0f / wsum[((size_t)b * D + d) * HW + p];
+        float acc = 0.0f;
+#pragma unroll
+        for (int g = 0; g < GL; ++g) {
+            const size_t at = (((size_t)b * G + h * GL + g) * D + d) * HW + p;
+            gd[g][d] = live ? gvol[at] * rden : 0.0f;
+            acc = fmaf(gd[g][d], vol[at], acc);
+        }
+        godot[d] = acc + __shfl_xor(acc, 1, kWave);          // sum over ALL groups: both lanes of the pixel
+    }
+    float dref[CL];
+#pragma unroll
+    for (int c = 0; c < CL; ++c) dref[c] = 0.0f;
+
+    for (int s = 0; s < dm.S; ++s) {
+        const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C + h * CL;
+        float* __restrict__ gsrcb = gsrcs.p[s] + (size_t)b * HWs * C;
+        const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
+        const Ray ray = rotate_pixel(q, fx, fy);
+        Taps taps[D];
+        float warped[CL][D], cor[GL][D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            taps[d] = project_taps(q, ray, hyp[d], dm.Hs, dm.Ws, half_w, half_h);
+            const Taps& t = taps[d];
+            const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
+            const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
+            const float4* __restrict__ p10 = reinterpret_cast<const float4*>(srcb + (size_t)t.o10 * C);
+            const float4* __restrict__ p11 = reinterpret_cast<const float4*>(srcb + (size_t)t.o11 * C);
+            float cg[GL];
+#pragma unroll
+            for (int g = 0; g < GL; ++g) cg[g] = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < CL4; ++c4) {
+                const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
+                const float4 r = refp[c4];
+                warped[4 * c4 + 0][d] = fmaf(dq.x, t.w11, fmaf(cq.x, t.w10, fmaf(bq.x, t.w01, a.x * t.w00)));
+                warped[4 * c4 + 1][d] = fmaf(dq.y, t.w11, fmaf(cq.y, t.w10, fmaf(bq.y, t.w01, a.y * t.w00)));
+                warped[4 * c4 + 2][d] = fmaf(dq.z, t.w11, fmaf(cq.z, t.w10, fmaf(bq.z, t.w01, a.z * t.w00)));
+                warped[4 * c4 + 3][d] = fmaf(dq.w, t.w11, fmaf(cq.w, t.w10, fmaf(bq.w, t.w01, a.w * t.w00)));
+                cg[(4 * c4 + 0) / CPG] = fmaf(warped[4 * c4 + 0][d], r.x, cg[(4 * c4 + 0) / CPG]);
+                cg[(4 * c4 + 1) / CPG] = fmaf(warped[4 * c4 + 1][d], r.y, cg[(4 * c4 + 1) / CPG]);
+                cg[(4 * c4 + 2) / CPG] = fmaf(warped[4 * c4 + 2][d], r.z, cg[(4 * c4 + 2) / CPG]);
+                cg[(4 * c4 + 3) / CPG] = fmaf(warped[4 * c4 + 3][d], r.w, cg[(4 * c4 + 3) / CPG]);
+            }
+#pragma unroll
+            for (int g = 0; g < GL; ++g) cor[g][d] = cg[g] * (1.0f / CPG);
+        }
+        float a[D], m = -INFINITY;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float sg = cor[0][d];
+#pragma unroll
+            for (int g = 1; g < GL; ++g) sg += cor[g][d];
+            // the reference sums the groups in order 0..G-1: lane 0 holds the first half, lane 1 the second
+            const float other = __shfl_xor(sg, 1, kWave);
+            sg = h == 0 ? sg + other : other + sg;
+            a[d] = sg / dm.temp;
+            m = fmaxf(m, a[d]);
+        }
+        float e[D], sum = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            e[d] = expf(a[d] - m);
+            sum += e[d];
+        }
+        float what[D], dw[D], sdot = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            what[d] = e[d] / sum;
+            float acc = 0.0f;
+#pragma unroll
+            for (int g = 0; g < GL; ++g) acc = fmaf(gd[g][d], cor[g][d], acc);
+            dw[d] = acc + __shfl_xor(acc, 1, kWave) - godot[d];
+            sdot = fmaf(what[d], dw[d], sdot);
+        }
+        bool have = false;
+        int xb = 0, yb = 0;
+        window_zero<CL>(mine);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float da = what[d] * (dw[d] - sdot) * inv_tc;
+            const float w = what[d] / dm.sqrt_c;
+            float dwarp[CL];
+#pragma unroll
+            for (int c4 = 0; c4 < CL4; ++c4) {
+                const float4 r = refp[c4];
+                const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * c4 + i;
+                    const float dcor = fmaf(gd[c / CPG][d], w, da) * (1.0f / CPG);
+                    dref[c] = fmaf(dcor, warped[c][d], dref[c]);
+                    dwarp[c] = dcor * rr[i];
+                }
+            }
+            const Taps& t = taps[d];
+            const bool active = live && t.mask != 0;
+            const int k = t.ix - xb;
+            const bool fits = have && t.iy == yb && k >= 0 && k <= 2;
+            const bool spill = active && have && !fits;          // identical in both lanes of a pixel
+            if (__any(spill)) {
+                *reinterpret_cast<int2*>(&mine[Wn::kDwords]) = make_int2((yb * dm.Ws + xb) * C, spill ? 1 : 0);
+                split_window_flush<C>(strip, lane, gsrcb, row_stride);
+                if (spill) {
+                    window_zero<CL>(mine);
+                    have = false;
+                }
+            }
+            if (active) {
+                if (!have) {
+                    xb = (taps[D - 1].ix < taps[0].ix) ? t.ix - 2 : t.ix;     // a pixel is a whole 64-byte line: no alignment
+                    yb = t.iy;
+                    have = true;
+                }
+                window_add<CL>(mine, t.ix - xb, t, dwarp);
+            }
+        }
+        *reinterpret_cast<int2*>(&mine[Wn::kDwords]) = make_int2((yb * dm.Ws + xb) * C, have ? 1 : 0);
+        split_window_flush<C>(strip, lane, gsrcb, row_stride);
+    }
+    float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C + h * CL);
+    if (live) {
+#pragma unroll
+        for (int c4 = 0; c4 < CL4; ++c4)
+            grefp[c4] = make_float4(dref[4 * c4 + 0], dref[4 * c4 + 1], dref[4 * c4 + 2], dref[4 * c4 + 3]);
+    }
+}
+
 template <int CPG, int G, int D, int DPL>
 static int launch_bwd(const float* gvol, const float* vol, const float* wsum, const float* ref, const SrcPtrs& srcs,
                       const float* pose, const float* hypo, float* gref, const GradPtrs& gsrcs, int B, VolumeDims dm,
@@ -455,6 +655,15 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
     constexpr int PXB = kBlock / (D / DPL);
     dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
+    if constexpr (CPG * G == 16 && DPL == 4 && D == 4) {
+        if (layout == MVSTER_LAYOUT_NHWC) {
+            dm.ntiles = grid_for((long long)dm.H * dm.W, kBlock / 2);           // two lanes per pixel
+            dim3 grid2(((dm.ntiles + 7) / 8) * 8, B);
+            hipLaunchKernelGGL((cost_volume_bwd_nhwc_split_kernel<16, G, 4>), grid2, dim3(kBlock), 0, st, gvol, vol, wsum,
+                               ref, srcs, pose, hypo, gref, gsrcs, dm);
+            return launch_status();
+        }
+    }
     if (layout == MVSTER_LAYOUT_NHWC)
         hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
                            ref, srcs, pose, hypo, gref, gsrcs, dm);
