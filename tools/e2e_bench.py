@@ -27,9 +27,13 @@ def main():
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--eval", action="store_true")
+    ap.add_argument("--benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (slow MIOpen find)")
     ap.add_argument("--bn", default="hip", choices=["hip", "native", "miopen"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    # the reference drivers set cudnn.benchmark = True (train_mvs4.py:16, test_mvs4.py:25); on ROCm that makes MIOpen run
+    # its exhaustive find for every convolution configuration -- the first step then takes more than 7 minutes
+    torch.backends.cudnn.benchmark = args.benchmark
     from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net as _m
     _m._BN_IMPL = args.bn
     torch.manual_seed(0)
