@@ -160,8 +160,8 @@ def kernel_symbol(entry, B, C, G, D, HW):
     csrc/cost_volume_common.h), as rocprofv3 prints it -- used to look the launch up in the PMC summary."""
     if entry in ("mvster_cost_volume_fwd", "mvster_cost_volume_bwd"):
         wide = entry.endswith("bwd") and D == 4 and C <= 16 and (B * HW) // 64 >= 8192
-        if wide and C == 16:
-            return "cost_volume_bwd_nhwc_split_kernel<16, %d, 4>" % G          # two lanes per pixel
+        if wide:
+            return "cost_volume_bwd_nhwc_split_kernel<%d, %d, 4>" % (C, G)     # two lanes per pixel
         return "cost_volume_%s_nhwc_kernel<%d, %d, %d, %d>" % (entry[-3:], C, G, D, D if wide else 1)
     return entry.replace("mvster_", "") + "_kernel"
 

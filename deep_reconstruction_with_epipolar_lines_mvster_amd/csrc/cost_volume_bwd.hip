@@ -269,24 +269,30 @@ __device__ __forceinline__ void window_add(float* __restrict__ mine, int k, cons
 }
 
 
-// flush of the two-lanes-per-pixel kernel (C = 16): source lanes 2k and 2k+1 hold channels 0-7 / 8-15 of the same
-// window; one wave-instruction adds one window row of the pair = 4 pixels x 16 channels = 256 contiguous bytes.
+// flush of the two-lanes-per-pixel kernels: source lanes 2k and 2k+1 hold the two channel halves of the same window;
+// one wave-instruction adds 64 contiguous dwords of the pair's window: one row (4 pixels x 16 channels) for C = 16,
+// both rows (2 x 4 pixels x 8 channels) for C = 8.
 template <int C>
-__device__ __forceinline__ void split_window_flush(float (*strip)[Window<8>::kStrip], int lane, float* __restrict__ gsrcb,
+__device__ __forceinline__ void split_window_flush(float (*strip)[Window<C / 2>::kStrip], int lane, float* __restrict__ gsrcb,
                                                    int row_stride) {
-    static_assert(C == 16, "split flush: two 8-channel halves per pixel");
-    using Wn = Window<8>;
+    static_assert(C == 16 || C == 8, "split flush: two channel halves per pixel");
+    constexpr int CL = C / 2;
+    using Wn = Window<CL>;
+    constexpr int RD = 4 * C;                 // dwords of one window row of the pair in memory
+    constexpr int RPI = kWave / RD;           // window rows per wave-instruction (1 or 2)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int px = lane >> 4, half = (lane >> 3) & 1, c = lane & 7;
+    const int in_row = lane % RD, sub_row = lane / RD;
+    const int px = in_row / C, ch = in_row % C, half = ch / CL, c = ch % CL;
     for (int k = 0; k < kWave / 2; ++k) {
         const int2 meta = *reinterpret_cast<const int2*>(&strip[2 * k][Wn::kDwords]);   // same address in every lane
         if (__builtin_amdgcn_readfirstlane(meta.y) == 0) continue;                     // wave-uniform
 #pragma unroll
-        for (int row = 0; row < 2; ++row) {
-            const float v = strip[2 * k + half][row * Wn::kRowDwords + px * 8 + c];
-            if (v != 0.0f) atomicAdd(gsrcb + (meta.x + row * row_stride + (lane & 63)), v);
+        for (int part = 0; part < 2 / RPI; ++part) {
+            const int row = part * RPI + sub_row;
+            const float v = strip[2 * k + half][row * Wn::kRowDwords + px * CL + c];
+            if (v != 0.0f) atomicAdd(gsrcb + (meta.x + row * row_stride + in_row), v);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -475,13 +481,13 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
 }
 
 
-// ------------------------------------------------------------------------------- backward, C = 16, two lanes per pixel
+// ------------------------------------------------------------------------------- backward, two lanes per pixel (C = 16, 8)
 // With 16 channels the one-lane-per-pixel kernel above needs a 128-dword window per lane (135 KB of LDS per workgroup)
 // and 256 VGPRs: one wave per SIMD, and it falls 35 % short of the atomic request ceiling.  Here a pixel is shared by
-// HS = 2 adjacent lanes, each owning 8 of the 16 channels (whole correlation groups): the per-lane window is the
-// C = 8 one (64 dwords), the workgroup is back to 70 KB of LDS / two workgroups per CU, and only the sums over ALL
-// groups (softmax input, dw) cross the lane pair (one xor-1 shuffle each).  The flush walks lane PAIRS so that one
-// wave-instruction still covers whole 64-byte pixels: 4 pixels x 16 channels = 256 contiguous bytes per row.
+// HS = 2 adjacent lanes, each owning half of the channels (whole correlation groups): the per-lane window halves
+// (64 dwords for C = 16), two or more workgroups fit a CU, and only the sums over ALL groups (softmax input, dw)
+// cross the lane pair (one xor-1 shuffle each).  The flush walks lane PAIRS so that one wave-instruction still
+// covers 256 contiguous bytes of whole 64-byte lines.
 template <int C, int G, int D>
 __global__ void __launch_bounds__(kBlock, 2)      // 70 KB of LDS admits two workgroups per CU: keep the registers there too
 cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* __restrict__ vol,
@@ -493,7 +499,7 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
     constexpr int CPG = C / G;
     constexpr int GL = G / HS;            // correlation groups per lane
     constexpr int CL4 = CL / 4;
-    static_assert(CL == 8 && CL % CPG == 0 && GL >= 1, "split kernel: 16 channels, whole groups per lane");
+    static_assert((C == 16 || C == 8) && CL % CPG == 0 && GL >= 1, "split kernel: whole correlation groups per lane");
     constexpr int PXB = kBlock / HS;
     using Wn = Window<CL>;
     __shared__ __attribute__((aligned(16))) float stage[kBlock / kWave][kWave][Wn::kStrip];
@@ -630,7 +636,8 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
             }
             if (active) {
                 if (!have) {
-                    xb = (taps[D - 1].ix < taps[0].ix) ? t.ix - 2 : t.ix;     // a pixel is a whole 64-byte line: no alignment
+                    constexpr int A = 16 / C;              // pixels per 64-byte line in memory: the window base is line-aligned
+                    xb = (taps[D - 1].ix < taps[0].ix) ? (((t.ix + 2 + (A - 1)) & ~(A - 1)) - 4) : (t.ix & ~(A - 1));
                     yb = t.iy;
                     have = true;
                 }
@@ -655,12 +662,12 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
     constexpr int PXB = kBlock / (D / DPL);
     dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
-    if constexpr (CPG * G == 16 && DPL == 4 && D == 4) {
+    if constexpr ((CPG * G == 16 || CPG * G == 8) && DPL == 4 && D == 4) {
         if (layout == MVSTER_LAYOUT_NHWC) {
             dm.ntiles = grid_for((long long)dm.H * dm.W, kBlock / 2);           // two lanes per pixel
             dim3 grid2(((dm.ntiles + 7) / 8) * 8, B);
-            hipLaunchKernelGGL((cost_volume_bwd_nhwc_split_kernel<16, G, 4>), grid2, dim3(kBlock), 0, st, gvol, vol, wsum,
-                               ref, srcs, pose, hypo, gref, gsrcs, dm);
+            hipLaunchKernelGGL((cost_volume_bwd_nhwc_split_kernel<CPG * G, G, 4>), grid2, dim3(kBlock), 0, st, gvol, vol,
+                               wsum, ref, srcs, pose, hypo, gref, gsrcs, dm);
             return launch_status();
         }
     }
