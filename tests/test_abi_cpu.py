@@ -90,3 +90,24 @@ def test_fused_support_table_matches_library(lib):
                 npp = ctypes.cast(null, ctypes.POINTER(ctypes.c_void_p))
                 rc = lib.mvster_cost_volume_fwd(one, npp, 1, one, one, one, one, 1, C, G, D, 8, 8, 8, 8, 2.0, 1, None)
                 assert (rc == 1) == rc_expected_supported, (C, G, D, rc)
+
+
+def test_header_is_plain_c_and_library_links_from_c(lib, tmp_path):
+    """gcc (not hipcc, not a C++ compiler) compiles a consumer of include/mvster_hip.h and links libmvster_hip.so."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "abi_smoke")
+    csrc = os.path.dirname(_lib.LIB_PATH)
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rocm_lib = "/opt/rocm/lib"
+    cmd = [gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_smoke.c"),
+           "-L", csrc, "-lmvster_hip", "-Wl,-rpath," + csrc, "-Wl,-rpath-link," + rocm_lib, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join([csrc, rocm_lib, torch_lib, os.environ.get("LD_LIBRARY_PATH", "")]))
+    r = subprocess.run([exe], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, "abi_smoke exited %d: %s %s" % (r.returncode, r.stdout, r.stderr)
+    assert "mvster C ABI v%d ok" % _lib.ABI_VERSION in r.stdout
