@@ -187,6 +187,20 @@ int mvster_bn_train_bwd(const float *dy, const float *x, const float *affine, co
                         const float *save_invstd, float *dx, float *dgamma, float *dbeta, double *sums, int N, int C,
                         int HW, int relu, mvster_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * F4  geometric consistency of a (reference, source) depth-map pair: project each reference pixel into the source
+ * view with its depth, sample the source depth bilinearly (constant border 0), project back, keep the pixel when the
+ * round trip lands within `pix_thresh` pixels and `depth_thresh` relative depth.  float64 per-pixel algebra like numpy.
+ * replaces: test_mvs4.py:612-670 (reproject_with_depth + check_geometric_consistency).  PARITY UNPINNED (cv2.remap).
+ *   depth_ref [H,W], depth_src [Hs,Ws] : device, fp32
+ *   mats : HOST pointer to 68 doubles, row-major: inv(K_ref)[3x3], E_src@inv(E_ref)[4x4], K_src, inv(K_src),
+ *          E_ref@inv(E_src)[4x4], K_ref
+ *   mask [H,W] uint8, depth_reproj [H,W] (0 where rejected), x_src, y_src [H,W] (both may be NULL) : device
+ */
+int mvster_geometric_consistency(const float *depth_ref, const float *depth_src, const double *mats, uint8_t *mask,
+                                 float *depth_reproj, float *x_src, float *y_src, int H, int W, int Hs, int Ws,
+                                 float pix_thresh, float depth_thresh, mvster_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
