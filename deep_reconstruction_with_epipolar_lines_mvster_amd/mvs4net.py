@@ -327,14 +327,26 @@ class MVS4net(nn.Module):
         # torch.channels_last keeps the FPN outputs in the layout the fused kernels gather from (zero-copy);
         # off by default: identical numerics either way, the conversion kernels cost ~1 % of a step
         self.channels_last_features = False
+        self.batch_views_in_eval = True
 
     def forward(self, imgs, proj_matrices, depth_values, filename=None):
         # step 1. feature extraction (stock PyTorch)
         features = []
-        for img in imgs:
+        if not self.training and self.batch_views_in_eval and len({tuple(i.shape) for i in imgs}) == 1:
+            # eval mode: BatchNorm uses its running statistics, so the N views are independent samples of one batch --
+            # one FPN pass over [N*B,3,H,W] instead of N passes (in training the reference normalises every view with
+            # its own batch statistics, so the views stay separate there)
+            stacked = torch.cat(list(imgs), 0)
             if self.channels_last_features:
-                img = img.contiguous(memory_format=torch.channels_last)
-            features.append(self.feature(img))
+                stacked = stacked.contiguous(memory_format=torch.channels_last)
+            pyramid = self.feature(stacked)
+            B = imgs[0].shape[0]
+            features = [{k: v[i * B:(i + 1) * B] for k, v in pyramid.items()} for i in range(len(imgs))]
+        else:
+            for img in imgs:
+                if self.channels_last_features:
+                    img = img.contiguous(memory_format=torch.channels_last)
+                features.append(self.feature(img))
         device, dtype = imgs[0].device, imgs[0].dtype
 
         # step 2. coarse-to-fine stages (HIP hot path)
