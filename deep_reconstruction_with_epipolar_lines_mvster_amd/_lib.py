@@ -15,6 +15,7 @@ _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
 _vpp = ctypes.POINTER(ctypes.c_void_p)
+_ll = ctypes.c_longlong
 
 # name -> argtypes, exactly the prototypes of include/mvster_hip.h
 PROTOTYPES = {
@@ -33,6 +34,8 @@ PROTOTYPES = {
     "mvster_sinkhorn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "mvster_bn_train_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp],
     "mvster_bn_train_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvster_bn_train_fwd_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _f, _i, _vp],
+    "mvster_bn_train_bwd_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "mvster_geometric_consistency": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "mvster_init_range": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_schedule_inverse_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -196,6 +196,171 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, c
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- channels-last variant
+// x is [M = N*H*W, C] (torch.channels_last storage), C a multiple of 4 and <= 64.  A lane owns one channel quad of a
+// row (16-byte loads); the kBlock / (C/4) rows of a workgroup-iteration are consecutive in memory, so every load and
+// store is a dense 4 KB burst.  Per-quad partial sums are reduced across the row-lanes through LDS.
+constexpr int kBnRowsPerBlock = 2048;      // rows a workgroup walks (grid.x = ceil(M / 2048))
+
+template <typename F>
+__device__ __forceinline__ void nhwc_rows(int M, int C4, F&& body) {
+    const int quad = threadIdx.x % C4, lane_row = threadIdx.x / C4, rows_per_iter = kBlock / C4;
+    const int first = blockIdx.x * kBnRowsPerBlock;
+    const int last = min(first + kBnRowsPerBlock, M);
+    if (lane_row >= rows_per_iter) return;                       // C4 does not divide kBlock only for odd C4 (not used)
+#pragma unroll 4
+    for (int r = first + lane_row; r < last; r += rows_per_iter) body(r, quad);
+}
+
+__device__ __forceinline__ void nhwc_reduce_quads(float (&acc)[8], double* __restrict__ sums, int C4, float* __restrict__ lds) {
+    // lanes of a wave with equal (lane % C4) own the same channel quad (C4 divides 64): butterfly over the strides >= C4,
+    // then one LDS slot per (wave, quad) and C4 threads fold the kBlock/64 waves and issue the double atomics
+    for (int off = 32; off >= C4; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < C4)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds[(wave * 16 + lane) * 8 + k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < kBlock / 64; ++w)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tot[k] += (double)lds[(w * 16 + threadIdx.x) * 8 + k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(&sums[2 * (4 * threadIdx.x + i)], tot[i]);
+            atomicAdd(&sums[2 * (4 * threadIdx.x + i) + 1], tot[4 + i]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+bn_stats_nhwc_kernel(const float* __restrict__ x, double* __restrict__ sums, int M, int C) {
+    __shared__ float lds[(kBlock / 64) * 16 * 8];
+    const int C4 = C / 4;
+    const float4 shift = reinterpret_cast<const float4*>(x)[threadIdx.x % C4];      // row 0 of this quad
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    nhwc_rows(M, C4, [&](int r, int quad) {
+        const float4 v = reinterpret_cast<const float4*>(x + (size_t)r * C)[quad];
+        const float a = v.x - shift.x, b = v.y - shift.y, c = v.z - shift.z, d = v.w - shift.w;
+        acc[0] += a; acc[1] += b; acc[2] += c; acc[3] += d;
+        acc[4] = fmaf(a, a, acc[4]); acc[5] = fmaf(b, b, acc[5]); acc[6] = fmaf(c, c, acc[6]); acc[7] = fmaf(d, d, acc[7]);
+    });
+    nhwc_reduce_quads(acc, sums, C4, lds);
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(kBlock)
+bn_apply_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ affine, const float* __restrict__ save_mean,
+                     float* __restrict__ y, int M, int C) {
+    const int C4 = C / 4, quad = threadIdx.x % C4;
+    float a[4], b[4], mu[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = affine[2 * (4 * quad + i)]; b[i] = affine[2 * (4 * quad + i) + 1]; mu[i] = save_mean[4 * quad + i]; }
+    nhwc_rows(M, C4, [&](int r, int q) {
+        float4 v = reinterpret_cast<const float4*>(x + (size_t)r * C)[q];
+        v.x = fmaf(v.x - mu[0], a[0], b[0]); v.y = fmaf(v.y - mu[1], a[1], b[1]);
+        v.z = fmaf(v.z - mu[2], a[2], b[2]); v.w = fmaf(v.w - mu[3], a[3], b[3]);
+        if (RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        reinterpret_cast<float4*>(y + (size_t)r * C)[q] = v;
+    });
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_stats_nhwc_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ affine,
+                         const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                         double* __restrict__ sums, int M, int C) {
+    __shared__ float lds[(kBlock / 64) * 16 * 8];
+    const int C4 = C / 4, quad = threadIdx.x % C4;
+    float a[4], b[4], mu[4], is[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = affine[2 * (4 * quad + i)]; b[i] = affine[2 * (4 * quad + i) + 1];
+        mu[i] = save_mean[4 * quad + i]; is[i] = save_invstd[4 * quad + i];
+    }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    nhwc_rows(M, C4, [&](int r, int q) {
+        const float4 xv = reinterpret_cast<const float4*>(x + (size_t)r * C)[q];
+        const float4 gv = reinterpret_cast<const float4*>(dy + (size_t)r * C)[q];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (RELU && !(fmaf(xs[i] - mu[i], a[i], b[i]) > 0.0f)) gs[i] = 0.0f;
+            acc[i] += gs[i];
+            acc[4 + i] = fmaf(gs[i], (xs[i] - mu[i]) * is[i], acc[4 + i]);
+        }
+    });
+    nhwc_reduce_quads(acc, sums, C4, lds);
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_apply_nhwc_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ affine,
+                         const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                         const double* __restrict__ sums, float* __restrict__ dx, float* __restrict__ dgamma,
+                         float* __restrict__ dbeta, int M, int C, double count) {
+    const int C4 = C / 4, quad = threadIdx.x % C4;
+    float a[4], b[4], mu[4], is[4], mdy[4], mdyx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = 4 * quad + i;
+        a[i] = affine[2 * c]; b[i] = affine[2 * c + 1]; mu[i] = save_mean[c]; is[i] = save_invstd[c];
+        mdy[i] = (float)(sums[2 * c] / count); mdyx[i] = (float)(sums[2 * c + 1] / count);
+        if (blockIdx.x == 0 && threadIdx.x < C4) {
+            if (dbeta != nullptr) dbeta[c] = (float)sums[2 * c];
+            if (dgamma != nullptr) dgamma[c] = (float)sums[2 * c + 1];
+        }
+    }
+    nhwc_rows(M, C4, [&](int r, int q) {
+        const float4 xv = reinterpret_cast<const float4*>(x + (size_t)r * C)[q];
+        const float4 gv = reinterpret_cast<const float4*>(dy + (size_t)r * C)[q];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        float gs[4] = {gv.x, gv.y, gv.z, gv.w}, o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (RELU && !(fmaf(xs[i] - mu[i], a[i], b[i]) > 0.0f)) gs[i] = 0.0f;
+            o[i] = a[i] * (gs[i] - mdy[i] - (xs[i] - mu[i]) * is[i] * mdyx[i]);
+        }
+        reinterpret_cast<float4*>(dx + (size_t)r * C)[q] = make_float4(o[0], o[1], o[2], o[3]);
+    });
+}
+
+// finalize for the channels-last layout: the shift sample of channel c is x[0*C + c]
+__global__ void bn_finalize_nhwc_kernel(const float* __restrict__ x, const double* __restrict__ sums,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                        float* __restrict__ affine, int C, double count, float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m1 = sums[2 * c] / count, m2 = sums[2 * c + 1] / count;
+    const double mean = (double)x[c] + m1;
+    double var = m2 - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    if (running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+    const float g = gamma != nullptr ? gamma[c] : 1.0f, b = beta != nullptr ? beta[c] : 0.0f;
+    affine[2 * c] = g * invstd;
+    affine[2 * c + 1] = b;
+}
+
+static int check_bn_nhwc(long long M, int C) {
+    MVSTER_REQUIRE_SHAPE(M > 0 && M <= (1LL << 31) - 1 && C > 0);
+    if (C % 4 != 0 || C > 64 || 64 % (C / 4) != 0) return MVSTER_ERR_UNSUPPORTED;    // C in {4, 8, 16, 32, 64}
+    return MVSTER_OK;
+}
+
 static int check_bn(int N, int C, int HW) {
     MVSTER_REQUIRE_SHAPE(N > 0 && N <= 65535 && C > 0 && C <= 65535 && HW > 0 && (long long)HW <= kMaxPlane);
     return MVSTER_OK;
@@ -240,6 +405,46 @@ extern "C" int mvster_bn_train_bwd(const float* dy, const float* x, const float*
     } else {
         hipLaunchKernelGGL((bn_bwd_stats_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, C, HW);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, dx, dgamma, dbeta, C, HW, count);
+    }
+    return launch_status();
+}
+
+extern "C" int mvster_bn_train_fwd_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                                        float* save_invstd, float* running_mean, float* running_var, double* sums,
+                                        float* affine, long long M, int C, float momentum, float eps, int relu,
+                                        mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(save_mean); MVSTER_REQUIRE_PTR(save_invstd);
+    MVSTER_REQUIRE_PTR(sums); MVSTER_REQUIRE_PTR(affine);
+    MVSTER_REQUIRE_SHAPE((running_mean == nullptr) == (running_var == nullptr));
+    if (int rc = check_bn_nhwc(M, C)) return rc;
+    const hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { (void)hipGetLastError(); return MVSTER_ERR_LAUNCH; }
+    dim3 grid(grid_for(M, kBnRowsPerBlock));
+    hipLaunchKernelGGL(bn_stats_nhwc_kernel, grid, dim3(kBlock), 0, st, x, sums, (int)M, C);
+    hipLaunchKernelGGL(bn_finalize_nhwc_kernel, dim3(grid_for(C, 64)), dim3(64), 0, st, x, sums, gamma, beta, save_mean,
+                       save_invstd, running_mean, running_var, affine, C, (double)M, momentum, eps);
+    if (relu) hipLaunchKernelGGL((bn_apply_nhwc_kernel<true>), grid, dim3(kBlock), 0, st, x, affine, save_mean, y, (int)M, C);
+    else hipLaunchKernelGGL((bn_apply_nhwc_kernel<false>), grid, dim3(kBlock), 0, st, x, affine, save_mean, y, (int)M, C);
+    return launch_status();
+}
+
+extern "C" int mvster_bn_train_bwd_nhwc(const float* dy, const float* x, const float* affine, const float* save_mean,
+                                        const float* save_invstd, float* dx, float* dgamma, float* dbeta, double* sums,
+                                        long long M, int C, int relu, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(dy); MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(affine); MVSTER_REQUIRE_PTR(save_mean);
+    MVSTER_REQUIRE_PTR(save_invstd); MVSTER_REQUIRE_PTR(dx); MVSTER_REQUIRE_PTR(sums);
+    if (int rc = check_bn_nhwc(M, C)) return rc;
+    const hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { (void)hipGetLastError(); return MVSTER_ERR_LAUNCH; }
+    dim3 grid(grid_for(M, kBnRowsPerBlock));
+    if (relu) {
+        hipLaunchKernelGGL((bn_bwd_stats_nhwc_kernel<true>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, (int)M, C);
+        hipLaunchKernelGGL((bn_bwd_apply_nhwc_kernel<true>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, dx, dgamma, dbeta, (int)M, C, (double)M);
+    } else {
+        hipLaunchKernelGGL((bn_bwd_stats_nhwc_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, (int)M, C);
+        hipLaunchKernelGGL((bn_bwd_apply_nhwc_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, dx, dgamma, dbeta, (int)M, C, (double)M);
     }
     return launch_status();
 }

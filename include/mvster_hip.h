@@ -187,6 +187,16 @@ int mvster_bn_train_bwd(const float *dy, const float *x, const float *affine, co
                         const float *save_invstd, float *dx, float *dgamma, float *dbeta, double *sums, int N, int C,
                         int HW, int relu, mvster_stream_t stream);
 
+/* The same two operations on channels-last storage: x, y, dy, dx are [M = N*H*W, C] row-major (torch.channels_last),
+ * C in {4, 8, 16, 32, 64} (else MVSTER_ERR_UNSUPPORTED).  All other arguments as above. */
+int mvster_bn_train_fwd_nhwc(const float *x, const float *gamma, const float *beta, float *y, float *save_mean,
+                             float *save_invstd, float *running_mean, float *running_var, double *sums,
+                             float *affine, long long M, int C, float momentum, float eps, int relu,
+                             mvster_stream_t stream);
+int mvster_bn_train_bwd_nhwc(const float *dy, const float *x, const float *affine, const float *save_mean,
+                             const float *save_invstd, float *dx, float *dgamma, float *dbeta, double *sums,
+                             long long M, int C, int relu, mvster_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * F4  geometric consistency of a (reference, source) depth-map pair: project each reference pixel into the source
  * view with its depth, sample the source depth bilinearly (constant border 0), project back, keep the pixel when the
