@@ -28,6 +28,9 @@ PROTOTYPES = {
     "mvster_cost_volume_fwd": [_vp, _vpp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "mvster_cost_volume_bwd": [_vp, _vp, _vp, _vp, _vpp, _i, _vp, _vp, _vp, _vpp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i,
                                _vp],
+    "mvster_cost_volume_bwd_ws": [_vp, _vp, _vp, _vp, _vpp, _i, _vp, _vp, _vp, _vpp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i,
+                                  _vp, _ll, _vp],
+    "mvster_cost_volume_bwd_workspace": [_i, _i, _i, _i, _i, _i, _i, _i],
     "mvster_depth_regress_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mvster_softmax_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvster_sinkhorn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
@@ -40,6 +43,8 @@ PROTOTYPES = {
     "mvster_init_range": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_schedule_inverse_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
 }
+
+RESTYPES = {"mvster_cost_volume_bwd_workspace": _ll}      # everything else returns the int status
 
 MVSTER_OK = 0
 LAYOUT_NCHW = 0
@@ -79,7 +84,7 @@ def load():
         for name, argtypes in PROTOTYPES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = RESTYPES.get(name, ctypes.c_int)
         lib.mvster_abi_version.restype = ctypes.c_int
         lib.mvster_error_string.restype = ctypes.c_char_p
         lib.mvster_error_string.argtypes = [ctypes.c_int]

@@ -301,19 +301,24 @@ __device__ __forceinline__ void split_window_flush(float (*strip)[Window<C / 2>:
 }
 
 // ------------------------------------------------------------------------------- backward, channels-last features
-template <int C, int G, int D, int DPL>
+// DEFER: the source-feature gradient is NOT scattered here.  The kernel stores, per (view, pixel, hypothesis), the G
+// group coefficients dcor (gradient w.r.t. the warped feature = dcor[group(c)] * ref[c]) into `dcor_out`
+// [B,S,HW,D,G]; tile_scatter_kernel (cost_volume_scatter.hip) recomputes the taps and does the scatter with a
+// wave-private write-combining cache in LDS.
+template <int C, int G, int D, int DPL, bool DEFER = false>
 __global__ void __launch_bounds__(kBlock)
 cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restrict__ vol,
                             const float* __restrict__ wsum, const float* __restrict__ ref, SrcPtrs srcs,
                             const float* __restrict__ pose, const float* __restrict__ hypo, float* __restrict__ gref,
-                            GradPtrs gsrcs, VolumeDims dm) {
+                            GradPtrs gsrcs, VolumeDims dm, float* __restrict__ dcor_out) {
     constexpr int CPG = C / G;
     constexpr int C4 = C / 4;
     constexpr int DL = D / DPL;
     constexpr int PXB = kBlock / DL;
+    static_assert(!DEFER || DPL == 1, "deferred scatter: one lane per (pixel, hypothesis)");
     constexpr bool kMergeDepths = (C <= 16 && DPL > 1);    // window merge of the hypotheses of a pixel (see above)
     constexpr int kRow = kMergeDepths ? Window<C>::kStrip : kStageRow;
-    __shared__ __attribute__((aligned(16))) float stage[kBlock / kWave][kWave][kRow];   // wave-private strips
+    __shared__ __attribute__((aligned(16))) float stage[DEFER ? 1 : kBlock / kWave][DEFER ? 1 : kWave][kRow];   // wave-private strips
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     if (tile >= dm.ntiles) return;
     const int b = blockIdx.y;
@@ -430,7 +435,16 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
                     dwarp[c] = dcor * rr[i];
                 }
             }
-            if constexpr (kMergeDepths) {
+            if constexpr (DEFER) {
+                if (live) {
+                    float* __restrict__ out = dcor_out + ((((size_t)b * dm.S + s) * HW + p) * D + (dl * DPL + j)) * G;
+#pragma unroll
+                    for (int g4 = 0; g4 < G / 4; ++g4)
+                        reinterpret_cast<float4*>(out)[g4] =
+                            make_float4(fmaf(gd[4 * g4 + 0][j], w, da) * (1.0f / CPG), fmaf(gd[4 * g4 + 1][j], w, da) * (1.0f / CPG),
+                                        fmaf(gd[4 * g4 + 2][j], w, da) * (1.0f / CPG), fmaf(gd[4 * g4 + 3][j], w, da) * (1.0f / CPG));
+                }
+            } else if constexpr (kMergeDepths) {
                 float (*strip)[kRow] = stage[threadIdx.x >> 6];
                 float* __restrict__ mine = strip[lane];
                 const Taps& t = taps[j];
@@ -655,6 +669,20 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
     }
 }
 
+// deferred route (see DEFER above): coefficients first, then the tiled scatter of cost_volume_scatter.hip
+template <int CPG, int G, int D>
+static int launch_bwd_deferred(const float* gvol, const float* vol, const float* wsum, const float* ref, const SrcPtrs& srcs,
+                               const float* pose, const float* hypo, float* gref, const GradPtrs& gsrcs, int B,
+                               VolumeDims dm, float* dcor, hipStream_t st) {
+    constexpr int PXB = kBlock / D;
+    dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
+    dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
+    hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, 1, true>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
+                       ref, srcs, pose, hypo, gref, gsrcs, dm, dcor);
+    if (int rc = launch_status()) return rc;
+    return launch_tile_scatter(dcor, ref, pose, hypo, gsrcs, B, CPG * G, G, D, dm, st);
+}
+
 template <int CPG, int G, int D, int DPL>
 static int launch_bwd(const float* gvol, const float* vol, const float* wsum, const float* ref, const SrcPtrs& srcs,
                       const float* pose, const float* hypo, float* gref, const GradPtrs& gsrcs, int B, VolumeDims dm,
@@ -673,7 +701,7 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
     }
     if (layout == MVSTER_LAYOUT_NHWC)
         hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
-                           ref, srcs, pose, hypo, gref, gsrcs, dm);
+                           ref, srcs, pose, hypo, gref, gsrcs, dm, static_cast<float*>(nullptr));
     else
         hipLaunchKernelGGL((cost_volume_bwd_kernel<CPG, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol, wsum, ref,
                            srcs, pose, hypo, gref, gsrcs, dm);
@@ -682,10 +710,26 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
 
 }  // namespace mvster
 
+extern "C" long long mvster_cost_volume_bwd_workspace(int S, int B, int C, int G, int D, int H, int W, int layout) {
+    using namespace mvster;
+    if (S <= 0 || B <= 0 || G <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (!tile_scatter_applies(C, G, D, layout)) return 0;
+    return (long long)B * S * H * W * D * G;
+}
+
 extern "C" int mvster_cost_volume_bwd(const float* gvol, const float* vol, const float* wsum, const float* ref,
                                       const float* const* srcs, int S, const float* pose, const float* hypo,
                                       float* gref, float* const* gsrcs, int B, int C, int G, int D, int H, int W,
                                       int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream) {
+    return mvster_cost_volume_bwd_ws(gvol, vol, wsum, ref, srcs, S, pose, hypo, gref, gsrcs, B, C, G, D, H, W, Hs, Ws,
+                                     attn_temp, layout, nullptr, 0, stream);
+}
+
+extern "C" int mvster_cost_volume_bwd_ws(const float* gvol, const float* vol, const float* wsum, const float* ref,
+                                         const float* const* srcs, int S, const float* pose, const float* hypo,
+                                         float* gref, float* const* gsrcs, int B, int C, int G, int D, int H, int W,
+                                         int Hs, int Ws, float attn_temp, int layout, float* workspace,
+                                         long long workspace_floats, mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(gvol); MVSTER_REQUIRE_PTR(vol); MVSTER_REQUIRE_PTR(wsum); MVSTER_REQUIRE_PTR(ref);
     MVSTER_REQUIRE_PTR(srcs); MVSTER_REQUIRE_PTR(pose); MVSTER_REQUIRE_PTR(hypo); MVSTER_REQUIRE_PTR(gref);
@@ -708,8 +752,14 @@ extern "C" int mvster_cost_volume_bwd(const float* gvol, const float* vol, const
     VolumeDims dm{H, W, Hs, Ws, S, 0, attn_temp, (float)sqrt((double)C)};
     const int cpg = C / G;
     const bool wide = pick_pixel_per_lane(B, H * W, C, D);
+    const long long need = mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, layout);
+    const bool deferred = need > 0 && workspace != nullptr && workspace_floats >= need;
 #define X(CPG_, G_)                                                                                                   \
     if (cpg == CPG_ && G == G_) {                                                                                     \
+        if constexpr (CPG_ * G_ >= 32) {                                                                              \
+            if (deferred && D == 8)                                                                                   \
+                return launch_bwd_deferred<CPG_, G_, 8>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, workspace, st); \
+        }                                                                                                             \
         if constexpr (CPG_ * G_ <= kMaxWideChannels) {                                                                \
             if (D == 4 && wide)                                                                                       \
                 return launch_bwd<CPG_, G_, 4, 4>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, layout, st);         \

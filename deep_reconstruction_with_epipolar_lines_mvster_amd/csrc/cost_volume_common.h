@@ -45,6 +45,15 @@ inline bool pick_pixel_per_lane(int B, int HW, int C, int D) {
     return D == 4 && C <= kMaxWideChannels && ((long long)B * HW) / kWave >= kMinPixelWaves;
 }
 
+// Tiled scatter of the deferred backward (cost_volume_scatter.hip): used for the coarse stages (D = 8 hypotheses
+// spread along the whole epipolar segment, C >= 32: one source pixel = 2-4 64-byte lines, no per-pixel merging possible).
+inline bool tile_scatter_applies(int C, int G, int D, int layout) {
+    return layout == MVSTER_LAYOUT_NHWC && D == 8 && (C == 32 || C == 64) && shape_instantiated(C, G, D);
+}
+
+int launch_tile_scatter(const float* dcor, const float* ref, const float* pose, const float* hypo, const GradPtrs& gsrcs,
+                        int B, int C, int G, int D, const VolumeDims& dm, hipStream_t st);
+
 inline int check_volume(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, float temp, int layout) {
     MVSTER_REQUIRE_SHAPE(layout == MVSTER_LAYOUT_NCHW || layout == MVSTER_LAYOUT_NHWC);
     MVSTER_REQUIRE_SHAPE(B > 0 && C > 0 && G > 0 && D > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && S > 0);

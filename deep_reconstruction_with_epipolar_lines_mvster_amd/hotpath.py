@@ -167,6 +167,9 @@ def to_planar(t):
     return out
 
 
+TILE_SCATTER = True      # backward of the coarse stages: coefficients + tiled LDS-merged scatter (see mvster_hip.h, A3)
+
+
 class _FusedCostVolume(torch.autograd.Function):
     """Feature maps may arrive NCHW-contiguous (the reference's FPN output) or channels_last.  The kernels
     gather from channels-last storage: NCHW inputs are converted once per call (and their gradients converted
@@ -212,11 +215,15 @@ class _FusedCostVolume(torch.autograd.Function):
         grads = [torch.empty_like(f) for f in feats]        # same storage layout as the kernel-side features
         pp, keep = _lib.ptr_array(srcs)
         gp, gkeep = _lib.ptr_array(grads[1:])
+        # scratch for the two-kernel route of the coarse stages (0 floats when it does not apply); torch's caching
+        # allocator owns it, the library never allocates
+        need = _lib.load().mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, layout) if TILE_SCATTER else 0
+        ws = torch.empty(need, dtype=torch.float32, device=ref.device) if need > 0 else None
         with _on(ref.device):
-            _lib.call("mvster_cost_volume_bwd", gvol.data_ptr(), vol.data_ptr(), wsum.data_ptr(), ref.data_ptr(), pp, S,
+            _lib.call("mvster_cost_volume_bwd_ws", gvol.data_ptr(), vol.data_ptr(), wsum.data_ptr(), ref.data_ptr(), pp, S,
                       pose.data_ptr(), hypo.data_ptr(), grads[0].data_ptr(), gp, B, C, G, D, H, W, Hs, Ws, attn_temp,
-                      layout, _stream(ref.device))
-        del keep, gkeep
+                      layout, ws.data_ptr() if ws is not None else None, need, _stream(ref.device))
+        del keep, gkeep, ws
         if layout == _lib.LAYOUT_NHWC:
             grads = [g if cl else to_planar(g) for g, cl in zip(grads, was_cl)]
         return (None, None, None, None, None) + tuple(grads)

@@ -115,6 +115,20 @@ int mvster_cost_volume_bwd(const float *gvol, const float *vol, const float *wsu
                            float *gref, float *const *gsrcs, int B, int C, int G, int D, int H, int W,
                            int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream);
 
+/* A3 with caller-provided scratch memory.  Same operation and results (to fp32 summation order); with a workspace
+ * of at least mvster_cost_volume_bwd_workspace(...) floats the coarse stages (channels-last, D = 8, C in {32,64})
+ * take the two-kernel route: per-hypothesis coefficients first, then a tiled scatter that merges the taps of an 8x8
+ * pixel block in LDS before they reach memory (4-9x fewer atomic requests).  workspace == NULL, a short workspace or
+ * any other shape: identical to mvster_cost_volume_bwd.  The library never allocates.
+ *   mvster_cost_volume_bwd_workspace : floats needed for this shape, 0 when the route does not apply.
+ */
+long long mvster_cost_volume_bwd_workspace(int S, int B, int C, int G, int D, int H, int W, int layout);
+int mvster_cost_volume_bwd_ws(const float *gvol, const float *vol, const float *wsum, const float *ref,
+                              const float *const *srcs, int S, const float *pose, const float *hypo,
+                              float *gref, float *const *gsrcs, int B, int C, int G, int D, int H, int W,
+                              int Hs, int Ws, float attn_temp, int layout, float *workspace,
+                              long long workspace_floats, mvster_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * A4  post-regnet half: softmax over depth, FIRST arg-max, depth gather, confidence, next range.
  * replaces: models/mvs4net_utils.py:1109-1113,1126-1138,1151-1156.

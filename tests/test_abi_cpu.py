@@ -92,6 +92,24 @@ def test_fused_support_table_matches_library(lib):
                 assert (rc == 1) == rc_expected_supported, (C, G, D, rc)
 
 
+def test_backward_workspace_query(lib):
+    """mvster_cost_volume_bwd_workspace is pure host arithmetic: B*S*H*W*D*G floats (the per-hypothesis group
+    coefficients) exactly for the shapes that take the two-kernel backward, 0 for every other shape or layout."""
+    q = lib.mvster_cost_volume_bwd_workspace          # (S, B, C, G, D, H, W, layout)
+    assert q(4, 4, 32, 8, 8, 296, 400, _lib.LAYOUT_NHWC) == 4 * 4 * 296 * 400 * 8 * 8
+    assert q(4, 1, 64, 8, 8, 148, 200, _lib.LAYOUT_NHWC) == 4 * 148 * 200 * 8 * 8
+    assert q(16, 65535, 64, 4, 8, 1184, 1600, _lib.LAYOUT_NHWC) == 16 * 65535 * 1184 * 1600 * 8 * 4     # > 2^32 floats
+    for args in ((4, 4, 32, 8, 8, 296, 400, _lib.LAYOUT_NCHW), (4, 4, 16, 4, 4, 592, 800, _lib.LAYOUT_NHWC),
+                 (4, 4, 8, 4, 4, 1184, 1600, _lib.LAYOUT_NHWC), (4, 4, 32, 8, 4, 296, 400, _lib.LAYOUT_NHWC),
+                 (4, 4, 48, 8, 8, 296, 400, _lib.LAYOUT_NHWC), (0, 4, 32, 8, 8, 296, 400, _lib.LAYOUT_NHWC),
+                 (4, 4, 32, 8, 8, 0, 400, _lib.LAYOUT_NHWC)):
+        assert q(*args) == 0
+    # the _ws entry point validates like the plain one before touching the device
+    rc = lib.mvster_cost_volume_bwd_ws(None, None, None, None, None, 1, None, None, None, None, 1, 32, 8, 8, 4, 4, 4, 4,
+                                       2.0, _lib.LAYOUT_NHWC, None, 0, None)
+    assert rc == 1          # MVSTER_ERR_NULL_POINTER
+
+
 def test_header_is_plain_c_and_library_links_from_c(lib, tmp_path):
     """gcc (not hipcc, not a C++ compiler) compiles a consumer of include/mvster_hip.h and links libmvster_hip.so."""
     import shutil

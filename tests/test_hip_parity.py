@@ -321,12 +321,14 @@ def test_layout_routes_agree(dev, C, G, D, H, W):
         close(results["nhwc_inplace"][1][i], results["nchw"][1][i], 1e-5, 1e-7, "grad feat%d in-place" % i)
 
 
-@pytest.mark.parametrize("stage,coherent", [(3, False), (3, True), (2, False), (2, True), (1, False), (1, True)])
+@pytest.mark.parametrize("stage,coherent", [(3, False), (3, True), (2, False), (2, True), (1, False), (1, True),
+                                            (0, False), (0, True)])
 def test_backward_scatter_paths_agree_full_size(dev, stage, coherent):
-    """The backward has three scatter paths chosen at run time: a workgroup LDS tile (spatially coherent depth), the
-    per-lane hypothesis window (C <= 16, one lane per pixel) and dense per-hypothesis strips.  At full DTU stage
-    shapes, spatially random hypotheses force the per-lane paths, smooth ones the tile path; both must give the
-    gradients of the planar (NCHW) kernel family, which scatters tap by tap."""
+    """The channels-last backward has several scatter paths: the per-lane hypothesis window (C <= 16, one or two lanes
+    per pixel), dense per-hypothesis strips, and - for the coarse stages (D = 8, C >= 32) when a workspace is passed -
+    the two-kernel route whose tiled scatter merges taps in a wave-private LDS cache (evictions on spatially random
+    hypotheses, mostly hits on smooth ones).  At full DTU stage shapes all of them must give the gradients of the
+    planar (NCHW) kernel family, which scatters tap by tap."""
     H, W, C, G, D, scale = DTU_STAGES[stage]
     feats, mats, hypo = dtu_inputs(H, W, C, D, scale, seed=60 + stage, S=2)
     if not coherent:
@@ -338,13 +340,27 @@ def test_backward_scatter_paths_agree_full_size(dev, stage, coherent):
     hy = hypo.to(dev)
     gvol = torch.randn(1, G, D, H, W, generator=torch.Generator().manual_seed(8)).to(dev)
     grads = {}
-    for route in ("nchw", "nhwc"):
+    from deep_reconstruction_with_epipolar_lines_mvster_amd import hotpath
+    seen = []
+    real_call = hotpath._lib.call
+    for route in ("nchw", "nhwc", "nhwc_direct"):
         fin = [f.to(dev).requires_grad_(True) for f in feats]
-        vol = mv.fused_cost_volume(fin, pose, hy, G, 2.0, layout=route)
-        vol.backward(gvol)
+        hotpath.TILE_SCATTER = route != "nhwc_direct"
+        hotpath._lib.call = lambda name, *a: (seen.append((route, name, a[-3])), real_call(name, *a))[1]
+        try:
+            vol = mv.fused_cost_volume(fin, pose, hy, G, 2.0, layout=route[:4])
+            vol.backward(gvol)
+        finally:
+            hotpath.TILE_SCATTER = True
+            hotpath._lib.call = real_call
         grads[route] = [f.grad for f in fin]
+    # the workspace pointer (third argument from the end) is passed exactly when the tiled route applies
+    ws = {r: a for r, n, a in seen if n == "mvster_cost_volume_bwd_ws"}
+    assert (ws["nhwc"] is not None) == (D == 8 and C >= 32) and ws["nhwc_direct"] is None and ws["nchw"] is None
+    tag = "stage%d %s" % (stage + 1, "smooth" if coherent else "random")
     for i in range(len(feats)):
-        close(grads["nhwc"][i], grads["nchw"][i], 2e-5, 1e-7, "stage%d %s grad feat%d" % (stage + 1, "smooth" if coherent else "random", i))
+        close(grads["nhwc"][i], grads["nchw"][i], 2e-5, 1e-7, "%s grad feat%d" % (tag, i))
+        close(grads["nhwc_direct"][i], grads["nchw"][i], 2e-5, 1e-7, "%s grad feat%d (direct)" % (tag, i))
 
 
 def test_identical_views_reduce_to_single_view(dev):
