@@ -67,7 +67,8 @@ struct __attribute__((aligned(16))) TapRecord {     // one (pixel, hypothesis), 
 template <int NSLOT, int D>
 __global__ void __launch_bounds__(kScatterBlock)
 tile_scatter_kernel(ScatterArgs a) {
-    static_assert(D == 8, "one tile row = 8 pixels x 8 hypotheses = one (pixel, hypothesis) per lane");
+    static_assert(D == 8 || D == 4, "a pass = 64 / D tile pixels x D hypotheses = one (pixel, hypothesis) per lane");
+    constexpr int kRowsPerPass = 8 / D;               // tile rows projected at once (1 or 2)
     constexpr int NB = NSLOT - kPad + 1;              // base entries 0 .. NB-1, taps reach NB-1+30 < NSLOT
     __shared__ int keys[kScatterBlock / kWave][NSLOT];
     __shared__ __attribute__((aligned(16))) float vals[kScatterBlock / kWave][NSLOT * kChunk];
@@ -94,107 +95,115 @@ tile_scatter_kernel(ScatterArgs a) {
 
     for (int i = lane; i < NSLOT; i += kWave) wkeys[i] = -1;
 
-    // phase-1 role of this lane: pixel column (lane >> 3) of the tile row, hypothesis (lane & 7)
-    const int px1 = lane >> 3, d1 = lane & 7;
+    // phase-1 role of this lane: tile row (within the pass) r1, pixel column px1, hypothesis d1
+    const int d1 = lane % D, px1 = (lane / D) & 7, r1 = lane / (8 * D);
     const int xr1 = x0 + px1;
-    const bool live1 = xr1 < dm.W;
-    const int x1 = live1 ? xr1 : dm.W - 1;
+    const bool live_x1 = xr1 < dm.W;
+    const int x1 = live_x1 ? xr1 : dm.W - 1;
     // phase-2 role: pixel columns 2 grp and 2 grp + 1 (the four groups of a step are two pixels apart, so that at a
     // source/reference scale near 1 their 2x2 footprints do not touch), channel c
     const int xa = min(x0 + 2 * grp, dm.W - 1), xb = min(x0 + 2 * grp + 1, dm.W - 1);
 
     const int rows = min(kTile, dm.H - y0);
-    for (int r = 0; r < rows; ++r) {
-        const int y = y0 + r;
-        // ---- phase 1: one projection per lane -------------------------------------------------------------------
-        {
-            const int p = y * dm.W + x1;
-            const Taps t = project_taps(q, rotate_pixel(q, (float)x1, (float)y), hypo[(size_t)d1 * HW + p], dm.Hs, dm.Ws,
-                                        half_w, half_h);
-            TapRecord rec;
-            const int e = t.ix + 29 * t.iy;                              // ix, iy >= -2
-            rec.entry = (e + 64 * NB) % NB;
-            rec.off = t.iy * dm.Ws + t.ix;
-            rec.pad0 = rec.pad1 = 0;
+    for (int rp = 0; rp < rows; rp += kRowsPerPass) {
+        // ---- phase 1: one projection per lane -----------------------------------------------------------------------
+        const int yr1 = y0 + rp + r1;
+        const bool live1 = live_x1 & (yr1 < dm.H);
+        const int y1 = min(yr1, dm.H - 1);
+        const int p1 = y1 * dm.W + x1;
+        const Taps t = project_taps(q, rotate_pixel(q, (float)x1, (float)y1), hypo[(size_t)d1 * HW + p1], dm.Hs, dm.Ws,
+                                    half_w, half_h);
+        TapRecord rec;
+        const int e = t.ix + 29 * t.iy;                              // ix, iy >= -2
+        rec.entry = (e + 64 * NB) % NB;
+        rec.off = t.iy * dm.Ws + t.ix;
+        rec.pad0 = rec.pad1 = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rec.w[k] = live1 ? masked_weight(t, k) : 0.0f;
-            const bool any = (rec.w[0] != 0.0f) | (rec.w[1] != 0.0f) | (rec.w[2] != 0.0f) | (rec.w[3] != 0.0f);
-            wave_sync();                                                 // the previous row's phase 2 is done with recs
-            wrecs[lane] = rec;
-            // does this (pixel, hypothesis) share a cache entry with the same hypothesis of another pixel of its step
-            // (pixels of equal parity)?
-            const int mine = any ? rec.entry : -100000 - 1000 * lane;
-            bool overlap = false;
+        for (int k = 0; k < 4; ++k) rec.w[k] = live1 ? masked_weight(t, k) : 0.0f;
+        const bool any1 = (rec.w[0] != 0.0f) | (rec.w[1] != 0.0f) | (rec.w[2] != 0.0f) | (rec.w[3] != 0.0f);
+        wave_sync();                                                 // the previous pass's phase 2 is done with recs
+        wrecs[lane] = rec;
+        // does this (pixel, hypothesis) share a cache entry with the same hypothesis of another pixel of its step
+        // (same row, pixels of equal parity)?
+        const int mine = any1 ? rec.entry : -100000 - 1000 * lane;
+        bool overlap = false;
 #pragma unroll
-            for (int j = 1; j < 4; ++j) {
-                const int other = __shfl(mine, (lane & 0x0f) | ((((px1 >> 1) + j) & 3) << 4), kWave);   // same parity, same d
-                overlap |= entries_overlap(mine, other);
-            }
-            // bit (pixel * 8 + d); a phase-2 step (parity, d) is serialised when any of its four pixels has its bit set
-            const unsigned long long clash_bits = __ballot(overlap);
-            wave_sync();
+        for (int j = 1; j < 4; ++j) {
+            const int pxo = (((px1 >> 1) + j) & 3) * 2 + (px1 & 1);
+            const int other = __shfl(mine, (r1 * 8 + pxo) * D + d1, kWave);
+            overlap |= entries_overlap(mine, other);
+        }
+        // bit = lane of the record; a phase-2 step is serialised when any of its four records has its bit set
+        const unsigned long long clash_bits = __ballot(overlap);
+        wave_sync();
 
-            // ---- phase 2: 16 steps, four (pixel, hypothesis) records per step -----------------------------------
-            const int pa = y * dm.W + xa, pb = y * dm.W + xb;
-            const float rva = a.ref[((size_t)b * HW + pa) * C + c], rvb = a.ref[((size_t)b * HW + pb) * C + c];
-            float dca[D], dcb[D];
+        // ---- phase 2: 16 steps, four (pixel, hypothesis) records per step -------------------------------------------
+        // step t: hypothesis t % D, pixel parity (t / D) & 1, row t / (2 D) of the pass; group g: pixel 2 g + parity
+        float rv[kRowsPerPass][2];
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                dca[d] = dcor[((size_t)pa * D + d) * G] * rva;
-                dcb[d] = dcor[((size_t)pb * D + d) * G] * rvb;
-            }
+        for (int rr = 0; rr < kRowsPerPass; ++rr) {
+            const int yy = min(y0 + rp + rr, dm.H - 1);
+            rv[rr][0] = a.ref[((size_t)b * HW + yy * dm.W + xa) * C + c];
+            rv[rr][1] = a.ref[((size_t)b * HW + yy * dm.W + xb) * C + c];
+        }
+        float dc[16];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+        for (int tstep = 0; tstep < 16; ++tstep) {
+            const int d = tstep % D, par = (tstep / D) & 1, rr = tstep / (2 * D);
+            const int yy = min(y0 + rp + rr, dm.H - 1);
+            const int pp = yy * dm.W + (par ? xb : xa);
+            dc[tstep] = dcor[((size_t)pp * D + d) * G] * rv[rr][par];
+        }
 #pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const TapRecord rc = wrecs[(2 * grp + h) * 8 + d];           // broadcast within the group
-                    const float base = h == 0 ? dca[d] : dcb[d];
-                    const unsigned long long step_bits = (0x0001000100010001ull << (8 * h)) << d;   // pixels h, h+2, h+4, h+6
-                    const bool clash = (clash_bits & step_bits) != 0;            // wave-uniform
-                    const bool any = (rc.w[0] != 0.0f) | (rc.w[1] != 0.0f) | (rc.w[2] != 0.0f) | (rc.w[3] != 0.0f);
-                    auto deposit4 = [&]() {
-                        const int e0 = rc.entry, e2 = rc.entry + 29;
-                        const int k0 = wkeys[e0], k1 = wkeys[e0 + 1], k2 = wkeys[e2], k3 = wkeys[e2 + 1];
-                        const float c0 = wvals[e0 * kChunk + cl], c1 = wvals[(e0 + 1) * kChunk + cl];
-                        const float c2 = wvals[e2 * kChunk + cl], c3 = wvals[(e2 + 1) * kChunk + cl];
-                        const int key[4] = {k0, k1, k2, k3};
-                        const float cur[4] = {c0, c1, c2, c3};
-                        const int off[4] = {rc.off, rc.off + 1, rc.off + dm.Ws, rc.off + dm.Ws + 1};
-                        float nv[4];
-                        int nk[4];
+        for (int tstep = 0; tstep < 16; ++tstep) {
+            const int d = tstep % D, par = (tstep / D) & 1, rr = tstep / (2 * D);
+            const TapRecord rc = wrecs[(rr * 8 + 2 * grp + par) * D + d];           // broadcast within the group
+            const float base = dc[tstep];
+            constexpr unsigned long long kQuad = 1ull | (1ull << (2 * D)) | (1ull << (4 * D)) | (1ull << (6 * D));
+            const unsigned long long step_bits = kQuad << ((rr * 8 + par) * D + d);
+            const bool clash = (clash_bits & step_bits) != 0;                        // wave-uniform
+            const bool any = (rc.w[0] != 0.0f) | (rc.w[1] != 0.0f) | (rc.w[2] != 0.0f) | (rc.w[3] != 0.0f);
+            auto deposit4 = [&]() {
+                const int e0 = rc.entry, e2 = rc.entry + 29;
+                const int k0 = wkeys[e0], k1 = wkeys[e0 + 1], k2 = wkeys[e2], k3 = wkeys[e2 + 1];
+                const float c0 = wvals[e0 * kChunk + cl], c1 = wvals[(e0 + 1) * kChunk + cl];
+                const float c2 = wvals[e2 * kChunk + cl], c3 = wvals[(e2 + 1) * kChunk + cl];
+                const int key[4] = {k0, k1, k2, k3};
+                const float cur[4] = {c0, c1, c2, c3};
+                const int off[4] = {rc.off, rc.off + 1, rc.off + dm.Ws, rc.off + dm.Ws + 1};
+                float nv[4];
+                int nk[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const bool act = rc.w[k] != 0.0f;
-                            const bool hit = key[k] == off[k];
-                            const float v = base * rc.w[k];
-                            if (act & !hit & (key[k] >= 0) & (cur[k] != 0.0f)) atomicAdd(gsrc + (size_t)key[k] * C, cur[k]);
-                            // an inactive tap of an active group rewrites its entry unchanged (the entry is reserved
-                            // for this group in this step either way)
-                            nv[k] = !act ? cur[k] : hit ? cur[k] + v : v;
-                            nk[k] = (act & !hit) ? off[k] : key[k];
-                        }
-                        wvals[e0 * kChunk + cl] = nv[0];
-                        wvals[(e0 + 1) * kChunk + cl] = nv[1];
-                        wvals[e2 * kChunk + cl] = nv[2];
-                        wvals[(e2 + 1) * kChunk + cl] = nv[3];
-                        if (cl == 0) {
-                            wkeys[e0] = nk[0];
-                            wkeys[e0 + 1] = nk[1];
-                            wkeys[e2] = nk[2];
-                            wkeys[e2 + 1] = nk[3];
-                        }
-                    };
-                    if (!clash) {
-                        if (any) deposit4();
-                    } else {
-                        for (int g = 0; g < 4; ++g) {
-                            if (any & (grp == g)) deposit4();
-                            wave_sync();
-                        }
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    const bool act = rc.w[k] != 0.0f;
+                    const bool hit = key[k] == off[k];
+                    const float v = base * rc.w[k];
+                    if (act & !hit & (key[k] >= 0) & (cur[k] != 0.0f)) atomicAdd(gsrc + (size_t)key[k] * C, cur[k]);
+                    // an inactive tap of an active group rewrites its entry unchanged (the entry is reserved
+                    // for this group in this step either way)
+                    nv[k] = !act ? cur[k] : hit ? cur[k] + v : v;
+                    nk[k] = (act & !hit) ? off[k] : key[k];
+                }
+                wvals[e0 * kChunk + cl] = nv[0];
+                wvals[(e0 + 1) * kChunk + cl] = nv[1];
+                wvals[e2 * kChunk + cl] = nv[2];
+                wvals[(e2 + 1) * kChunk + cl] = nv[3];
+                if (cl == 0) {
+                    wkeys[e0] = nk[0];
+                    wkeys[e0 + 1] = nk[1];
+                    wkeys[e2] = nk[2];
+                    wkeys[e2 + 1] = nk[3];
+                }
+            };
+            if (!clash) {
+                if (any) deposit4();
+            } else {
+                for (int g = 0; g < 4; ++g) {
+                    if (any & (grp == g)) deposit4();
                     wave_sync();
                 }
             }
+            wave_sync();
         }
     }
 
@@ -216,6 +225,9 @@ int launch_tile_scatter(const float* dcor, const float* ref, const float* pose, 
     ScatterArgs a{dcor, ref, pose, hypo, gsrcs, dm, C, G, D, grid_for(dm.W, 2 * kTile)};
     const int tiles_y = grid_for(dm.H, kTile);
     dim3 grid(a.tiles_x * tiles_y, B, dm.S * (C / kChunk));
+    // The kernel also handles D = 4 (two tile rows per pass).  Measured on the stage-3 shape (C = 16, B = 4): coefficient
+    // kernel 1.12 ms + scatter 2.21 ms = 3.39 ms against 3.30 ms for the two-lanes-per-pixel window kernel - the scatter
+    // is instruction-bound (0.28 us per four records) before the saved requests pay off, so it is not dispatched.
     if (D != 8) return MVSTER_ERR_UNSUPPORTED;
     // 128 entries per wave (10.5 KB): measured best on MI355X against 96/160/192/256 - more entries merge more taps but
     // leave fewer waves per CU to hide the LDS round trips (stage 2, B=4: 3.54 / 3.32 / 3.80 / 3.77 / 4.03 ms)
