@@ -363,6 +363,43 @@ def test_backward_scatter_paths_agree_full_size(dev, stage, coherent):
         close(grads["nhwc_direct"][i], grads["nchw"][i], 2e-5, 1e-7, "%s grad feat%d (direct)" % (tag, i))
 
 
+@pytest.mark.parametrize("C,G,S,B,H,W,Hs,Ws", [(32, 8, 3, 3, 13, 21, 13, 21), (64, 8, 16, 1, 9, 17, 11, 15),
+                                               (32, 4, 2, 2, 8, 16, 8, 16), (64, 4, 1, 2, 23, 7, 20, 9)])
+def test_tiled_scatter_edge_cases_vs_oracle(dev, C, G, S, B, H, W, Hs, Ws):
+    """Two-kernel backward of the coarse stages (D = 8) on awkward shapes: tiles cut by the right / bottom border,
+    source maps of another size, the maximum view count times four channel chunks (grid.z = 64), one view entirely
+    outside the source map, a zero upstream gradient for one hypothesis: gradients of every feature map against the
+    CPU oracle's autograd, and the workspace route must have been the one that ran."""
+    from deep_reconstruction_with_epipolar_lines_mvster_amd import hotpath
+    D = 8
+    g = torch.Generator().manual_seed(C + S + H)
+    feats = [0.7 * torch.randn(B, C, H, W, generator=g)] + [0.7 * torch.randn(B, C, Hs, Ws, generator=g) for _ in range(S)]
+    mats = synth_views(B, S + 1, H, W, scale=W / 1600.0, yaw_deg=1.0)
+    mats[:, :, 0, :2, 3] *= 0.15
+    if S >= 2:
+        mats[:, S, 0, 0, 3] = 1e6                                   # last view: every projection leaves the map
+    base = 1.0 / (520 + 300 * torch.rand(B, 1, H, W, generator=g))
+    hypo = (1.0 / (base + (torch.arange(D).view(1, D, 1, 1) - (D - 1) / 2) * 8e-5)).contiguous()
+    gw = torch.randn(B, G, D, H, W, generator=g)
+    gw[:, :, 3] = 0.0
+    cf = [f.clone().requires_grad_(True) for f in feats]
+    (orc.fuse_source_views(cf, mats, hypo, True, G, 2.0, True) * gw).sum().backward()
+    gf = [f.to(dev).requires_grad_(True) for f in feats]
+    seen = []
+    real_call = hotpath._lib.call
+    hotpath._lib.call = lambda name, *a: (seen.append((name, a[-3])), real_call(name, *a))[1]
+    try:
+        vol = mv.fused_cost_volume(gf, mv.stage_poses(mats.to(dev)), hypo.to(dev), G, 2.0)
+        (vol * gw.to(dev)).sum().backward()
+    finally:
+        hotpath._lib.call = real_call
+    assert [a for n, a in seen if n == "mvster_cost_volume_bwd_ws"] not in ([], [None])
+    for i in range(S + 1):
+        close(gf[i].grad, cf[i].grad, 1e-4, 1e-7, "tiled scatter C%d S%d grad feat%d" % (C, S, i))
+    if S >= 2:
+        assert float(gf[S].grad.abs().max()) == 0.0
+
+
 def test_identical_views_reduce_to_single_view(dev):
     """Size-independent property at the full stage-4 shape: fusing S copies of one source view gives the
     single-view correlation (num/den = S w cor / (1e-8 + S w))."""
