@@ -15,6 +15,7 @@ reference's outputs / input-gradients for the hot-path functions of SURVEY.md se
   ties.npz        arg-max tie behaviour of the post-regnet half (:1126-1130)
   sinkhorn_*.npz, loss_mvs4net.npz  sinkhorn (:1164-1210) and MVS4net_loss (models/MVS4Net.py:195-240)
   model_e2e_64.npz  MVS4net (models/MVS4Net.py:16-193) seeded construction checksums, eval + train forward, 64x64
+  pfm_io.npz      save_pfm / read_pfm (datasets/data_io.py:6-71): file bytes written and arrays read back
 """
 import math
 import os
@@ -336,7 +337,34 @@ def make_model():
     save("model_e2e_64", **arrays)
 
 
+def make_pfm():
+    """PFM files as the reference's datasets/data_io.py writes them (bytes) and reads them back (arrays).  The module's
+    only other top-level import is cv2 (stubbed above); read_pfm / save_pfm use numpy alone."""
+    import tempfile
+    from datasets.data_io import read_pfm, save_pfm
+    g = np.random.default_rng(7)
+    cases = {"grey": (g.standard_normal((5, 7)) * 300 + 600).astype(np.float32),
+             "grey1": g.standard_normal((3, 4, 1)).astype(np.float32),
+             "colour": g.standard_normal((4, 3, 3)).astype(np.float32),
+             "bigendian": (g.standard_normal((2, 6)) * 10).astype(">f4")}
+    arrays = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, img in cases.items():
+            path = os.path.join(tmp, name + ".pfm")
+            save_pfm(path, img, scale=1 if name != "colour" else 2.5)
+            back, scale = read_pfm(path)
+            arrays[name + "_image"] = img.astype(np.float32) if name == "bigendian" else img
+            arrays[name + "_bytes"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+            arrays[name + "_read"] = np.ascontiguousarray(back).astype(np.float32)
+            arrays[name + "_scale"] = np.float64(scale)
+    np.savez_compressed(os.path.join(HERE, "pfm_io.npz"), **arrays)
+    print("pfm_io.npz", {k: v.shape for k, v in arrays.items()})
+
+
 if __name__ == "__main__":
+    if "--pfm-only" in sys.argv:
+        make_pfm()
+        sys.exit(0)
     if "--model-only" in sys.argv:
         make_model()
         sys.exit(0)
@@ -349,3 +377,4 @@ if __name__ == "__main__":
     make_ties()
     make_sinkhorn()
     make_model()
+    make_pfm()
