@@ -26,7 +26,10 @@ namespace mvster {
 
 constexpr int kTile = 8;            // reference pixels per wave tile edge
 constexpr int kChunk = 16;          // channels per cache entry: one 64-byte line
-constexpr int kPad = 32;            // entries e .. e+30 of one hypothesis never wrap: the arrays are padded instead
+// entry distance of vertically adjacent source pixels; swept 13 / 17 / 21 / 29 / 37 / 45 on the bench inputs: stage-2
+// backward 3.21 / 3.24 / 3.36 / 3.28 / 3.35 / 3.83 ms, stage 1 1.50 / 1.58 / 1.65 / 1.49 / 1.63 / 2.11 ms (flat below ~30)
+constexpr int kRowStep = 29;
+constexpr int kPad = kRowStep + 3;  // entries e .. e+kRowStep+1 of one hypothesis never wrap: the arrays are padded instead
 constexpr int kScatterBlock = 128;  // two waves = a 16 x 8 pixel tile per workgroup (LDS, not threads, limits residency)
 
 struct ScatterArgs {
@@ -49,12 +52,12 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // The four taps of one hypothesis are the source pixels (ix,iy) (ix+1,iy) (ix,iy+1) (ix+1,iy+1).  With the entry index
-// e = (ix + 29 iy) mod NB they occupy the four DIFFERENT entries e, e+1, e+29, e+30 (no wrap: kPad spare entries), so a
+// e = (ix + kRowStep iy) mod NB they occupy the four DIFFERENT entries e, e+1, e+29, e+30 (no wrap: kPad spare entries), so a
 // group deposits its four taps as one batch with all LDS reads in flight together.  Two groups can touch the same entry
 // only when their base entries differ by 0, 1, 28, 29 or 30.
 __device__ __forceinline__ bool entries_overlap(int ea, int eb) {
     const int diff = abs(ea - eb);
-    return (diff <= 1) | ((diff >= 28) & (diff <= 30));
+    return (diff <= 1) | ((diff >= kRowStep - 1) & (diff <= kRowStep + 1));
 }
 
 struct __attribute__((aligned(16))) TapRecord {     // one (pixel, hypothesis), written by one lane, read by a 16-lane group
@@ -114,8 +117,8 @@ tile_scatter_kernel(ScatterArgs a) {
         const Taps t = project_taps(q, rotate_pixel(q, (float)x1, (float)y1), hypo[(size_t)d1 * HW + p1], dm.Hs, dm.Ws,
                                     half_w, half_h);
         TapRecord rec;
-        const int e = t.ix + 29 * t.iy;                              // ix, iy >= -2
-        rec.entry = (e + 64 * NB) % NB;
+        const int e = t.ix + kRowStep * t.iy;                        // ix, iy >= -2
+        rec.entry = (e + 128 * NB) % NB;
         rec.off = t.iy * dm.Ws + t.ix;
         rec.pad0 = rec.pad1 = 0;
 #pragma unroll
@@ -164,7 +167,7 @@ tile_scatter_kernel(ScatterArgs a) {
             const bool clash = (clash_bits & step_bits) != 0;                        // wave-uniform
             const bool any = (rc.w[0] != 0.0f) | (rc.w[1] != 0.0f) | (rc.w[2] != 0.0f) | (rc.w[3] != 0.0f);
             auto deposit4 = [&]() {
-                const int e0 = rc.entry, e2 = rc.entry + 29;
+                const int e0 = rc.entry, e2 = rc.entry + kRowStep;
                 const int k0 = wkeys[e0], k1 = wkeys[e0 + 1], k2 = wkeys[e2], k3 = wkeys[e2 + 1];
                 const float c0 = wvals[e0 * kChunk + cl], c1 = wvals[(e0 + 1) * kChunk + cl];
                 const float c2 = wvals[e2 * kChunk + cl], c3 = wvals[(e2 + 1) * kChunk + cl];
