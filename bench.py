@@ -161,7 +161,7 @@ def kernel_symbol(entry, B, C, G, D, HW):
     if entry in ("mvster_cost_volume_fwd", "mvster_cost_volume_bwd"):
         wide = entry.endswith("bwd") and D == 4 and C <= 16 and (B * HW) // 64 >= 8192
         if wide:
-            return "cost_volume_bwd_nhwc_split_kernel<%d, %d, 4>" % (C, G)     # two lanes per pixel
+            return "cost_volume_bwd_nhwc_split_kernel<%d, %d, 4, %d>" % (C, G, 4 if C == 16 else 2)   # 2 or 4 lanes per pixel
         if entry.endswith("bwd") and D == 8 and C >= 32:
             return "tile_scatter_kernel<128, 8>"     # two-kernel route; the scatter half is the longer one
         return "cost_volume_%s_nhwc_kernel<%d, %d, %d, %d>" % (entry[-3:], C, G, D, D if wide else 1)

@@ -269,29 +269,29 @@ __device__ __forceinline__ void window_add(float* __restrict__ mine, int k, cons
 }
 
 
-// flush of the two-lanes-per-pixel kernels: source lanes 2k and 2k+1 hold the two channel halves of the same window;
-// one wave-instruction adds 64 contiguous dwords of the pair's window: one row (4 pixels x 16 channels) for C = 16,
-// both rows (2 x 4 pixels x 8 channels) for C = 8.
-template <int C>
-__device__ __forceinline__ void split_window_flush(float (*strip)[Window<C / 2>::kStrip], int lane, float* __restrict__ gsrcb,
+// flush of the several-lanes-per-pixel kernels: source lanes HS*k .. HS*k+HS-1 hold the HS channel parts of the same
+// window; one wave-instruction adds 64 contiguous dwords of the pixel's window: one row (4 pixels x 16 channels) for
+// C = 16, both rows (2 x 4 pixels x 8 channels) for C = 8.
+template <int C, int HS>
+__device__ __forceinline__ void split_window_flush(float (*strip)[Window<C / HS>::kStrip], int lane, float* __restrict__ gsrcb,
                                                    int row_stride) {
-    static_assert(C == 16 || C == 8, "split flush: two channel halves per pixel");
-    constexpr int CL = C / 2;
+    static_assert(C == 16 || C == 8, "split flush: whole 64-byte lines per wave-instruction");
+    constexpr int CL = C / HS;
     using Wn = Window<CL>;
-    constexpr int RD = 4 * C;                 // dwords of one window row of the pair in memory
+    constexpr int RD = 4 * C;                 // dwords of one window row of the pixel in memory
     constexpr int RPI = kWave / RD;           // window rows per wave-instruction (1 or 2)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int in_row = lane % RD, sub_row = lane / RD;
-    const int px = in_row / C, ch = in_row % C, half = ch / CL, c = ch % CL;
-    for (int k = 0; k < kWave / 2; ++k) {
-        const int2 meta = *reinterpret_cast<const int2*>(&strip[2 * k][Wn::kDwords]);   // same address in every lane
-        if (__builtin_amdgcn_readfirstlane(meta.y) == 0) continue;                     // wave-uniform
+    const int px = in_row / C, ch = in_row % C, part = ch / CL, c = ch % CL;
+    for (int k = 0; k < kWave / HS; ++k) {
+        const int2 meta = *reinterpret_cast<const int2*>(&strip[HS * k][Wn::kDwords]);   // same address in every lane
+        if (__builtin_amdgcn_readfirstlane(meta.y) == 0) continue;                      // wave-uniform
 #pragma unroll
-        for (int part = 0; part < 2 / RPI; ++part) {
-            const int row = part * RPI + sub_row;
-            const float v = strip[2 * k + half][row * Wn::kRowDwords + px * CL + c];
+        for (int step = 0; step < 2 / RPI; ++step) {
+            const int row = step * RPI + sub_row;
+            const float v = strip[HS * k + part][row * Wn::kRowDwords + px * CL + c];
             if (v != 0.0f) atomicAdd(gsrcb + (meta.x + row * row_stride + in_row), v);
         }
     }
@@ -502,14 +502,17 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
 // (64 dwords for C = 16), two or more workgroups fit a CU, and only the sums over ALL groups (softmax input, dw)
 // cross the lane pair (one xor-1 shuffle each).  The flush walks lane PAIRS so that one wave-instruction still
 // covers 256 contiguous bytes of whole 64-byte lines.
-template <int C, int G, int D>
+template <int C>
+constexpr int kSplitLanes = (C == 16) ? 4 : 2;    // C = 16: four lanes per pixel (4 channels = one float4 per tap and lane)
+
+template <int C, int G, int D, int HS>           // HS = lanes per pixel (2 or 4)
 __global__ void __launch_bounds__(kBlock, 2)      // 70 KB of LDS admits two workgroups per CU: keep the registers there too
 cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* __restrict__ vol,
                                   const float* __restrict__ wsum, const float* __restrict__ ref, SrcPtrs srcs,
                                   const float* __restrict__ pose, const float* __restrict__ hypo,
                                   float* __restrict__ gref, GradPtrs gsrcs, VolumeDims dm) {
-    constexpr int HS = 2;                 // lanes per pixel
-    constexpr int CL = C / HS;            // channels per lane (8)
+    static_assert(HS == 2 || HS == 4, "two or four lanes per pixel");
+    constexpr int CL = C / HS;            // channels per lane
     constexpr int CPG = C / G;
     constexpr int GL = G / HS;            // correlation groups per lane
     constexpr int CL4 = CL / 4;
@@ -547,7 +550,7 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
             gd[g][d] = live ? gvol[at] * rden : 0.0f;
             acc = fmaf(gd[g][d], vol[at], acc);
         }
-        godot[d] = acc + __shfl_xor(acc, 1, kWave);          // sum over ALL groups: both lanes of the pixel
+        godot[d] = group_sum<HS>(acc);                       // sum over ALL groups: every lane of the pixel
     }
     float dref[CL];
 #pragma unroll
@@ -593,9 +596,17 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
             float sg = cor[0][d];
 #pragma unroll
             for (int g = 1; g < GL; ++g) sg += cor[g][d];
-            // the reference sums the groups in order 0..G-1: lane 0 holds the first half, lane 1 the second
-            const float other = __shfl_xor(sg, 1, kWave);
-            sg = h == 0 ? sg + other : other + sg;
+            // the reference sums the groups in order 0..G-1: lane h of the pixel holds the h-th part
+            if constexpr (HS == 2) {
+                const float other = __shfl_xor(sg, 1, kWave);
+                sg = h == 0 ? sg + other : other + sg;
+            } else {
+                const int first = lane & ~(HS - 1);
+                float tot = __shfl(sg, first, kWave);
+#pragma unroll
+                for (int i = 1; i < HS; ++i) tot += __shfl(sg, first + i, kWave);
+                sg = tot;
+            }
             a[d] = sg / dm.temp;
             m = fmaxf(m, a[d]);
         }
@@ -612,7 +623,7 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
             float acc = 0.0f;
 #pragma unroll
             for (int g = 0; g < GL; ++g) acc = fmaf(gd[g][d], cor[g][d], acc);
-            dw[d] = acc + __shfl_xor(acc, 1, kWave) - godot[d];
+            dw[d] = group_sum<HS>(acc) - godot[d];
             sdot = fmaf(what[d], dw[d], sdot);
         }
         bool have = false;
@@ -639,10 +650,10 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
             const bool active = live && t.mask != 0;
             const int k = t.ix - xb;
             const bool fits = have && t.iy == yb && k >= 0 && k <= 2;
-            const bool spill = active && have && !fits;          // identical in both lanes of a pixel
+            const bool spill = active && have && !fits;          // identical in all lanes of a pixel
             if (__any(spill)) {
                 *reinterpret_cast<int2*>(&mine[Wn::kDwords]) = make_int2((yb * dm.Ws + xb) * C, spill ? 1 : 0);
-                split_window_flush<C>(strip, lane, gsrcb, row_stride);
+                split_window_flush<C, HS>(strip, lane, gsrcb, row_stride);
                 if (spill) {
                     window_zero<CL>(mine);
                     have = false;
@@ -659,7 +670,7 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
             }
         }
         *reinterpret_cast<int2*>(&mine[Wn::kDwords]) = make_int2((yb * dm.Ws + xb) * C, have ? 1 : 0);
-        split_window_flush<C>(strip, lane, gsrcb, row_stride);
+        split_window_flush<C, HS>(strip, lane, gsrcb, row_stride);
     }
     float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C + h * CL);
     if (live) {
@@ -692,9 +703,10 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
     if constexpr ((CPG * G == 16 || CPG * G == 8) && DPL == 4 && D == 4) {
         if (layout == MVSTER_LAYOUT_NHWC) {
-            dm.ntiles = grid_for((long long)dm.H * dm.W, kBlock / 2);           // two lanes per pixel
+            constexpr int HS = kSplitLanes<CPG * G>;                            // lanes per pixel
+            dm.ntiles = grid_for((long long)dm.H * dm.W, kBlock / HS);
             dim3 grid2(((dm.ntiles + 7) / 8) * 8, B);
-            hipLaunchKernelGGL((cost_volume_bwd_nhwc_split_kernel<CPG * G, G, 4>), grid2, dim3(kBlock), 0, st, gvol, vol,
+            hipLaunchKernelGGL((cost_volume_bwd_nhwc_split_kernel<CPG * G, G, 4, HS>), grid2, dim3(kBlock), 0, st, gvol, vol,
                                wsum, ref, srcs, pose, hypo, gref, gsrcs, dm);
             return launch_status();
         }
