@@ -495,13 +495,14 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
 }
 
 
-// ------------------------------------------------------------------------------- backward, two lanes per pixel (C = 16, 8)
+// ------------------------------------------------------------------------------- backward, several lanes per pixel (C = 16, 8)
 // With 16 channels the one-lane-per-pixel kernel above needs a 128-dword window per lane (135 KB of LDS per workgroup)
 // and 256 VGPRs: one wave per SIMD, and it falls 35 % short of the atomic request ceiling.  Here a pixel is shared by
-// HS = 2 adjacent lanes, each owning half of the channels (whole correlation groups): the per-lane window halves
-// (64 dwords for C = 16), two or more workgroups fit a CU, and only the sums over ALL groups (softmax input, dw)
-// cross the lane pair (one xor-1 shuffle each).  The flush walks lane PAIRS so that one wave-instruction still
-// covers 256 contiguous bytes of whole 64-byte lines.
+// HS adjacent lanes, each owning C / HS channels (whole correlation groups): the per-lane window shrinks accordingly,
+// several workgroups fit a CU, and only the sums over ALL groups (softmax input, dw) cross the lanes of a pixel (xor
+// shuffles).  The flush walks the lane groups so that one wave-instruction still covers 256 contiguous bytes of whole
+// 64-byte lines.  Measured (B = 4): C = 16 with two lanes per pixel 256 VGPRs, 8 waves per CU, 3.30 ms (17.2 G atomic
+// requests/s); with four lanes 154 VGPRs, 12 waves per CU, 2.93 ms (19.3 G/s).  C = 8: two lanes (a lane loads float4s).
 template <int C>
 constexpr int kSplitLanes = (C == 16) ? 4 : 2;    // C = 16: four lanes per pixel (4 channels = one float4 per tap and lane)
 
