@@ -769,7 +769,7 @@ extern "C" int mvster_cost_volume_bwd_ws(const float* gvol, const float* vol, co
     const bool deferred = need > 0 && workspace != nullptr && workspace_floats >= need;
 #define X(CPG_, G_)                                                                                                   \
     if (cpg == CPG_ && G == G_) {                                                                                     \
-        if constexpr (CPG_ * G_ >= 32) {                                                                              \
+        if constexpr (CPG_ * G_ >= 16) {                                                                              \
             if (deferred && D == 8)                                                                                   \
                 return launch_bwd_deferred<CPG_, G_, 8>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, workspace, st); \
         }                                                                                                             \

@@ -45,10 +45,12 @@ inline bool pick_pixel_per_lane(int B, int HW, int C, int D) {
     return D == 4 && C <= kMaxWideChannels && ((long long)B * HW) / kWave >= kMinPixelWaves;
 }
 
-// Tiled scatter of the deferred backward (cost_volume_scatter.hip): used for the coarse stages (D = 8 hypotheses
-// spread along the whole epipolar segment, C >= 32: one source pixel = 2-4 64-byte lines, no per-pixel merging possible).
+// Tiled scatter of the deferred backward (cost_volume_scatter.hip): used for the stages with D = 8 hypotheses spread
+// along the whole epipolar segment (no per-pixel merging possible).  Measured against the direct kernels (B x S views):
+// DTU stage 2 (C = 32) 6.72 -> 3.31 ms, stage 1 (C = 64) 2.17 -> 1.47 ms; hi-res config stage 3 (768 x 1024, C = 16,
+// 1 x 9 views) 8.76 -> 6.94 ms, stage 2 (384 x 512, C = 32, 1 x 9) 4.83 -> 2.93 ms (tools/probes/hires_bwd_probe.py).
 inline bool tile_scatter_applies(int C, int G, int D, int layout) {
-    return layout == MVSTER_LAYOUT_NHWC && D == 8 && (C == 32 || C == 64) && shape_instantiated(C, G, D);
+    return layout == MVSTER_LAYOUT_NHWC && D == 8 && (C == 16 || C == 32 || C == 64) && shape_instantiated(C, G, D);
 }
 
 int launch_tile_scatter(const float* dcor, const float* ref, const float* pose, const float* hypo, const GradPtrs& gsrcs,

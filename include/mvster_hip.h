@@ -116,7 +116,7 @@ int mvster_cost_volume_bwd(const float *gvol, const float *vol, const float *wsu
                            int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream);
 
 /* A3 with caller-provided scratch memory.  Same operation and results (to fp32 summation order); with a workspace
- * of at least mvster_cost_volume_bwd_workspace(...) floats the coarse stages (channels-last, D = 8, C in {32,64})
+ * of at least mvster_cost_volume_bwd_workspace(...) floats the stages with D = 8 hypotheses (channels-last, C in {16,32,64})
  * take the two-kernel route: per-hypothesis coefficients first, then a tiled scatter that merges the taps of an 8x8
  * pixel block in LDS before they reach memory (4-9x fewer atomic requests).  workspace == NULL, a short workspace or
  * any other shape: identical to mvster_cost_volume_bwd.  The library never allocates.

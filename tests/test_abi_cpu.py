@@ -98,6 +98,7 @@ def test_backward_workspace_query(lib):
     q = lib.mvster_cost_volume_bwd_workspace          # (S, B, C, G, D, H, W, layout)
     assert q(4, 4, 32, 8, 8, 296, 400, _lib.LAYOUT_NHWC) == 4 * 4 * 296 * 400 * 8 * 8
     assert q(4, 1, 64, 8, 8, 148, 200, _lib.LAYOUT_NHWC) == 4 * 148 * 200 * 8 * 8
+    assert q(9, 1, 16, 4, 8, 768, 1024, _lib.LAYOUT_NHWC) == 9 * 768 * 1024 * 8 * 4          # hi-res config, stage 3
     assert q(16, 65535, 64, 4, 8, 1184, 1600, _lib.LAYOUT_NHWC) == 16 * 65535 * 1184 * 1600 * 8 * 4     # > 2^32 floats
     for args in ((4, 4, 32, 8, 8, 296, 400, _lib.LAYOUT_NCHW), (4, 4, 16, 4, 4, 592, 800, _lib.LAYOUT_NHWC),
                  (4, 4, 8, 4, 4, 1184, 1600, _lib.LAYOUT_NHWC), (4, 4, 32, 8, 4, 296, 400, _lib.LAYOUT_NHWC),
