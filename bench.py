@@ -3,7 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
 
-One process per GPU (torch.distributed over RCCL when launched by torch.distributed.run).  A "step" is one
+One process per GPU.  `python bench.py --gpus N` with N > 1 starts its own N ranks (fresh child processes, spawned
+before the parent makes any GPU call) unless a launcher (torch.distributed.run) already did; ranks talk over
+RCCL (torch.distributed backend "nccl").  A "step" is one
 forward + backward pass of the hot path over one batch of reference views at the four literal DTU stage
 shapes (1600x1184, 1 ref + 4 src views, D = 8,8,4,4, G = 8,8,4,4):
 
@@ -12,18 +14,23 @@ shapes (1600x1184, 1 ref + 4 src views, D = 8,8,4,4, G = 8,8,4,4; SURVEY.md sect
   backward: softmax backward -> stub regnet backward -> fused cost-volume backward (A3, fp32 atomics).
 
 Every rank works on its own batch (units = reference views, no data-path collective).  With more than one rank
-the step ends with the only exchange the reference has in training: an all-reduce of a 1,009,119-element fp32
-gradient vector (the reference model's parameter count; its DDP bucket), over RCCL/xGMI.
+the step carries the only exchange the reference has in training, DDP's gradient all-reduce (train_mvs4.py:562-570):
+1,009,119 fp32 per step, here as four asynchronous all-reduces issued from autograd hooks the moment a stage's
+backward has produced its reference-feature gradient (payload: the leading elements of that gradient), so that the
+collectives overlap the rest of the backward like DDP's buckets do; the step waits for them at its end.
 
 Prints ONE JSON line on rank 0 (see README / the driver contract) with two extra objects:
   roofline     -- dominant kernel's algorithmic HBM bytes per launch / its average duration (HIP events on the
                   launch stream, collected over the timed steps) against the 8 TB/s HBM peak;
   cpu_baseline -- the CPU oracle (same torch operator sequence as the reference's CPU path, kind "port")
-                  timed on this host's cores on a bounded sample (one reference view, one pass).
+                  timed on this host's cores on a bounded sample (one reference view; 1 warm-up + 3 timed passes, median).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from collections import defaultdict
@@ -155,33 +162,53 @@ def algorithmic_bytes(entry, B, C, G, D, HW, S):
     return 0
 
 
-def kernel_symbol(entry, B, C, G, D, HW):
-    """Name of the gfx950 kernel an ABI entry point launches for this shape (mirrors pick_pixel_per_lane() in
-    csrc/cost_volume_common.h), as rocprofv3 prints it -- used to look the launch up in the PMC summary."""
-    if entry in ("mvster_cost_volume_fwd", "mvster_cost_volume_bwd"):
-        wide = entry.endswith("bwd") and D == 4 and C <= 16 and (B * HW) // 64 >= 8192
-        if wide:
-            return "cost_volume_bwd_nhwc_split_kernel<%d, %d, 4, %d>" % (C, G, 4 if C == 16 else 2)   # 2 or 4 lanes per pixel
-        if entry.endswith("bwd") and D == 8 and C >= 32:
-            return "tile_scatter_kernel<128, 8>"     # two-kernel route; the scatter half is the longer one
-        return "cost_volume_%s_nhwc_kernel<%d, %d, %d, %d>" % (entry[-3:], C, G, D, D if wide else 1)
+def kernel_symbol(entry, B, C, G, D, H, W, S):
+    """Name of the dominant gfx950 kernel an ABI entry point launches for this shape, as rocprofv3 prints it.  The
+    backward's route comes from the library itself (mvster_cost_volume_bwd_route), not from a mirror of its rules."""
+    if entry == "mvster_cost_volume_bwd":
+        need = _lib.load().mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC)
+        return _lib.bwd_route(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC, need)[2]
+    if entry == "mvster_cost_volume_fwd":
+        return "cost_volume_fwd_nhwc_kernel<%d, %d, %d, 1>" % (C, G, D)
     return entry.replace("mvster_", "") + "_kernel"
 
 
-def pmc_traffic(symbol, path=None):
+def source_fingerprint():
+    """sha256 over the kernel sources and the ABI header: ties a committed PMC summary to the code it was taken from."""
+    import glob
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "deep_reconstruction_with_epipolar_lines_mvster_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + \
+            [os.path.join(ROOT, "include", "mvster_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(symbol, path=None, fingerprint=None):
     """HBM bytes per launch of `symbol` from the newest committed PMC summary (tools/pmc_summary.py: separate
     rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE of this same bench command, gfx950 corrections applied).
-    None when no summary covers the kernel."""
+    Returns (bytes, file, entry, reason): bytes is None -- with the reason -- when no summary covers the kernel or when
+    the summary was taken from other kernel sources than the ones in this tree (its "_meta.csrc_sha" differs)."""
     import glob
     files = [path] if path else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    fingerprint = fingerprint or source_fingerprint()
+    reason = "no PMC summary under profiles/ lists %s" % symbol
     for f in reversed(files):
         try:
-            entry = json.load(open(f)).get(symbol)
+            doc = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if entry and "hbm_bytes_per_launch" in entry:
-            return entry["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), entry
-    return None, None, None
+        entry = doc.get(symbol)
+        if not (entry and "hbm_bytes_per_launch" in entry):
+            continue
+        rel = os.path.relpath(f, ROOT)
+        have = (doc.get("_meta") or {}).get("csrc_sha")
+        if have != fingerprint:
+            reason = "%s was collected from kernel sources %s, this tree is %s: stale, re-run tools/pmc_pass.sh" % (rel, have, fingerprint)
+            continue
+        return entry["hbm_bytes_per_launch"], rel, entry, None
+    return None, None, None, reason
 
 
 class LaunchTimer:
@@ -215,10 +242,10 @@ class LaunchTimer:
     def shape_key(name, args):
         if name == "mvster_cost_volume_fwd":
             B, C, G, D, H, W = args[7:13]
-            return (B, C, G, D, H * W, args[2])
+            return (B, C, G, D, H * W, args[2], H, W)
         if name == "mvster_cost_volume_bwd":
             B, C, G, D, H, W = args[10:16]
-            return (B, C, G, D, H * W, args[5])
+            return (B, C, G, D, H * W, args[5], H, W)
         if name == "mvster_depth_regress_fwd":
             B, D, H, W = args[8:12]
             return (B, 0, 0, D, H * W, 0)
@@ -237,9 +264,10 @@ class LaunchTimer:
         rows = []
         for (name, key), evs in self.records.items():
             ms = [a.elapsed_time(b) for a, b in evs]
-            B, C, G, D, HW, S = key
+            B, C, G, D, HW, S = key[:6]
+            H, W = key[6:8] if len(key) >= 8 else (0, 0)
             nbytes = algorithmic_bytes(name, B, C, G, D, HW, S)
-            rows.append(dict(entry=name, B=B, C=C, G=G, D=D, HW=HW, S=S, launches=len(ms), avg_ms=sum(ms) / len(ms),
+            rows.append(dict(entry=name, B=B, C=C, G=G, D=D, HW=HW, S=S, H=H, W=W, launches=len(ms), avg_ms=sum(ms) / len(ms),
                              total_ms=sum(ms), algorithmic_bytes=nbytes))
         rows.sort(key=lambda r: -r["total_ms"])
         return rows
@@ -287,13 +315,27 @@ def cpu_baseline():
             loss = loss + (prev["attn_weight"] * lw).sum()
         loss.backward()
 
-    one_pass([0])                      # warm the operator caches on the smallest stage (untimed)
-    t0 = time.perf_counter()
-    one_pass([0, 1, 2, 3])
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "ref-views/s", "cores": cores, "kind": "port",
-            "sample": "1 reference view (B=1), DTU 1600x1184 S=4 D=(8,8,4,4), all 4 stages fwd+bwd, 1 timed pass "
-                      "(%.1f s) of oracle/mvster_oracle.py with %d torch threads" % (dt, cores)}
+    one_pass([0, 1, 2, 3])             # one full untimed warm-up pass
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        one_pass([0, 1, 2, 3])
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
+    return {"value": 1.0 / dt, "unit": "ref-views/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": "1 reference view (B=1), DTU 1600x1184 S=4 D=(8,8,4,4), all 4 stages fwd+bwd of oracle/mvster_oracle.py "
+                      "with %d torch threads: 1 warm-up + 3 timed passes (%s s), median %.1f s"
+                      % (cores, " / ".join("%.1f" % t for t in times), dt)}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def device_sync(device):
@@ -332,6 +374,99 @@ def rank_seed(rank):
     return 1234 + rank
 
 
+# ---------------------------------------------------------------------------------- multi-rank launch and exchange
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv, timeout_s=1500.0, program=None):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters, so none inherits GPU
+    state -- this parent has made no HIP call), wait for all of them, relay rank 0's JSON line.  Any rank failing
+    terminates the others and makes the parent exit non-zero.  Returns the exit code."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, program or os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + timeout_s
+    rc = 0
+    pending = set(range(n))
+    out0 = b""
+    try:
+        while pending and rc == 0:
+            for r in sorted(pending):
+                if r == 0:
+                    try:
+                        out0 += procs[0].communicate(timeout=0.2)[0] or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    print("bench.py: rank %d exited with %d" % (r, code), file=sys.stderr, flush=True)
+                    rc = code if code > 0 else 1
+            if time.time() > deadline:
+                print("bench.py: ranks still running after %.0f s" % timeout_s, file=sys.stderr, flush=True)
+                rc = 124
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+# DDP's gradient traffic per step in the reference: 1,009,119 fp32 parameters (SURVEY section 5).  Split by the stage whose
+# backward produces them last-to-first (stage 4 first): reg.3 / reg.2 / reg.1 / reg.0 + feature + mono head.
+EXCHANGE_BUCKETS = [195_345, 195_345, 195_345, DDP_GRAD_ELEMS - 3 * 195_345]     # issued after stage 4, 3, 2, 1 backward
+
+
+class GradientExchange:
+    """Stand-in for DistributedDataParallel on the hot-path benchmark (which has no parameters: the regnet is a stub).
+    One asynchronous all-reduce per stage, issued from an autograd hook as soon as that stage's backward has written its
+    reference-feature gradient; the payload is the leading elements of that gradient (real gradient data, the byte count
+    of the reference's DDP traffic).  The collectives run on RCCL's stream and overlap the backward kernels of the
+    remaining stages; wait() joins them at the end of the step."""
+
+    def __init__(self, stages):
+        self.work = []
+        self.elems = 0
+        self.buffers = []
+        order = list(range(len(stages) - 1, -1, -1))                 # backward visits stage 4 first
+        for n, k in zip(EXCHANGE_BUCKETS, order):
+            leaf = stages[k]["feats"][0]
+            n = min(n, leaf.numel())
+            buf = torch.empty(n, dtype=torch.float32, device=leaf.device)
+            self.buffers.append(buf)
+            self.elems += n
+            leaf.register_hook(self._hook(buf, n))
+
+    def _hook(self, buf, n):
+        def on_grad(grad):
+            buf.copy_(grad.reshape(-1)[:n])
+            self.work.append(dist.all_reduce(buf, async_op=True))
+            return None
+        return on_grad
+
+    def wait(self):
+        for w in self.work:
+            w.wait()
+        self.work.clear()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,18 +482,26 @@ def main():
                          "(RCCL refuses two ranks on one device); exercises the N>1 control path, not a measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one.  Nothing above has touched the GPU (imports only).
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    distributed = "WORLD_SIZE" in os.environ        # a launcher started us: join its process group, even when it has one rank
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    backend = None
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = "gloo" if args.rehearse_on_one_gpu else "nccl"
+        if backend == "gloo":
             dist.init_process_group(backend="gloo", init_method="env://")
         else:
             dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
@@ -367,14 +510,14 @@ def main():
     B = args.batch
     stages, dv = make_inputs(B, seed=rank_seed(rank), device=device, data=args.data)
     net = mv.stagenet(inverse_depth=True, mono=True, attn_fuse_d=True, attn_temp=ATTN_TEMP).train()
-    grad_vec = torch.zeros(DDP_GRAD_ELEMS, device=device) if world > 1 else None
+    exchange = GradientExchange(stages) if distributed else None
     timer = LaunchTimer()
     timer.install()
 
     def step():
         hot_path_step(stages, dv, net, device)
-        if grad_vec is not None:
-            dist.all_reduce(grad_vec)
+        if exchange is not None:
+            exchange.wait()
 
     timer.enabled = False
     for _ in range(args.warmup):
@@ -383,6 +526,12 @@ def main():
     elapsed = timed_region(step, args.steps, 0, device, world)
     timer.enabled = False
 
+    ranks_seen = world
+    if distributed:
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())
+
     if rank == 0:
         rows = timer.summary()
         dom = rows[0]
@@ -390,8 +539,11 @@ def main():
         kernels = [{"entry": r["entry"], "shape": "B%d C%d G%d D%d px%d S%d" % (r["B"], r["C"], r["G"], r["D"], r["HW"], r["S"]),
                     "avg_ms": round(r["avg_ms"], 4), "launches": r["launches"],
                     "GBps": round(r["algorithmic_bytes"] / (r["avg_ms"] * 1e-3) / 1e9, 1)} for r in rows[:8]]
-        symbol = kernel_symbol(dom["entry"], dom["B"], dom["C"], dom["G"], dom["D"], dom["HW"])
-        traffic, traffic_src, pmc = pmc_traffic(symbol) if (B == 4 and args.data == "noise") else (None, None, None)
+        symbol = kernel_symbol(dom["entry"], dom["B"], dom["C"], dom["G"], dom["D"], dom["H"], dom["W"], dom["S"])
+        if B == 4 and args.data == "noise":
+            traffic, traffic_src, pmc, why = pmc_traffic(symbol)
+        else:
+            traffic, traffic_src, pmc, why = None, None, None, "PMC summaries are collected for --batch 4 --data noise only"
         out = {
             "metric": "reference-views/sec (fwd+bwd), DTU 1600x1184 N=5 D=(8,8,4,4)",
             "value": whole_job_rate(world, B, args.steps, elapsed),
@@ -405,17 +557,25 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if args.data == "noise" else "synthetic (multi-view-consistent scene features)",
+            "scope": "hot path only: the regnet callback is a stub (reg2d is illegal at H=1184, SURVEY 8d); the end-to-end "
+                     "training step is measured by tools/e2e_bench.py (DESIGN.md section 5)",
             "config": {"workload": "MVSTER cost-volume hot path fwd+bwd (stub regnet), DTU 1600x1184 stage shapes "
                                    "148x200/296x400/592x800/1184x1600, 1 ref + 4 src views, D=(8,8,4,4), G=(8,8,4,4), "
                                    "C=(64,32,16,8), inverse depth, attn_temp 2",
                        "ref_views_per_gpu_per_step": B, "global_batch": B * world,
-                       "exchange": "none" if world == 1 else "all-reduce of 1,009,119 fp32 (DDP gradient bucket) per step"},
+                       "exchange": "none" if exchange is None else
+                       "%d fp32 per step (the reference's DDP gradient volume) as %d async all-reduces over %s issued from "
+                       "autograd hooks as each stage's backward completes (payload: leading elements of that stage's "
+                       "reference-feature gradient); stand-in for DDP, the hot path has no parameters"
+                       % (exchange.elems, len(exchange.buffers), backend),
+                       "ranks_seen_by_collective": ranks_seen},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src and (traffic_src + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
-                                                            "separate passes of this command (B=4), bytes = 2*FETCH_KiB*1024 + "
-                                                            "WRITE_KiB*1024 (gfx950 FETCH_SIZE halving verified on kernels "
-                                                            "with known byte counts)"),
+                         "traffic_source": (traffic_src + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of "
+                                            "this command (B=4), bytes = 2*FETCH_KiB*1024 + WRITE_KiB*1024 (gfx950 FETCH_SIZE "
+                                            "halving verified on kernels with known byte counts); source fingerprint matches")
+                         if traffic_src else None,
+                         "traffic_null_reason": why,
                          "atomic_requests_per_launch": pmc and pmc.get("TCC_EA0_ATOMIC_sum_avg"),
                          # the backward is bound by the chip-wide float-atomic REQUEST rate (64-byte requests executed at
                          # the memory side: 1.3 TB/s / 64 B, MI355X_MICROARCH.md "Global float atomics"), not by HBM bytes
@@ -433,7 +593,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -31,6 +31,8 @@ PROTOTYPES = {
     "mvster_cost_volume_bwd_ws": [_vp, _vp, _vp, _vp, _vpp, _i, _vp, _vp, _vp, _vpp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i,
                                   _vp, _ll, _vp],
     "mvster_cost_volume_bwd_workspace": [_i, _i, _i, _i, _i, _i, _i, _i],
+    "mvster_cost_volume_bwd_route": [_i, _i, _i, _i, _i, _i, _i, _i, _ll],
+    "mvster_cost_volume_bwd_route_name": [_i, _i, _i, _i, ctypes.c_char_p, _i],
     "mvster_depth_regress_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mvster_softmax_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvster_sinkhorn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
@@ -112,6 +114,18 @@ def try_call(name, *args):
     if rc != MVSTER_OK:
         raise MvsterError(name, rc, lib.mvster_error_string(rc).decode())
     return True
+
+
+BWD_ROUTES = {0: "none", 1: "planar", 2: "dense", 3: "split_window", 4: "tile_scatter"}
+
+
+def bwd_route(S, B, C, G, D, H, W, layout, workspace_floats):
+    """(route id, route label, dominant kernel symbol as rocprofv3 prints it) the backward entry point picks."""
+    lib = load()
+    rid = lib.mvster_cost_volume_bwd_route(S, B, C, G, D, H, W, layout, workspace_floats)
+    buf = ctypes.create_string_buffer(128)
+    lib.mvster_cost_volume_bwd_route_name(rid, C, G, D, buf, len(buf))
+    return rid, BWD_ROUTES.get(rid, "route%d" % rid), buf.value.decode()
 
 
 def ptr_array(tensors):

@@ -1,5 +1,7 @@
 // A3  backward of the fused cost-volume kernel (see cost_volume_fwd.hip for the work decomposition).
 //   reference: autograd of models/mvs4net_utils.py:1036-1102, exercised by loss.backward() (train_mvs4.py:344).
+#include <stdio.h>
+
 #include "cost_volume_common.h"
 
 namespace mvster {
@@ -222,30 +224,6 @@ __device__ __forceinline__ void window_zero(float* __restrict__ mine) {
     for (int q = 0; q < Window<C>::kDwords / 4; ++q) w4[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-// adds the window of every source lane whose flag is set; all 64 lanes of the wave must call it
-template <int C>
-__device__ __forceinline__ void window_flush(float (*strip)[Window<C>::kStrip], int lane, float* __restrict__ gsrcb,
-                                             int row_stride) {
-    using Wn = Window<C>;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int sl = 0; sl < kWave; ++sl) {
-        const int2 meta = *reinterpret_cast<const int2*>(&strip[sl][Wn::kDwords]);   // same address in every lane
-        if (__builtin_amdgcn_readfirstlane(meta.y) == 0) continue;                  // wave-uniform
-#pragma unroll
-        for (int part = 0; part < Wn::kDwords / kWave; ++part) {
-            const int e = part * kWave + lane;
-            const int dy = e / Wn::kRowDwords, in_row = e % Wn::kRowDwords;
-            const float v = strip[sl][e];
-            if (v != 0.0f) atomicAdd(gsrcb + (meta.x + dy * row_stride + in_row), v);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // accumulate one hypothesis (4 taps x C channels) into the lane's window at pixel offset k (0..2)
 template <int C>
 __device__ __forceinline__ void window_add(float* __restrict__ mine, int k, const Taps& t, const float (&dwarp)[C]) {
@@ -315,9 +293,8 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
     constexpr int C4 = C / 4;
     constexpr int DL = D / DPL;
     constexpr int PXB = kBlock / DL;
-    static_assert(!DEFER || DPL == 1, "deferred scatter: one lane per (pixel, hypothesis)");
-    constexpr bool kMergeDepths = (C <= 16 && DPL > 1);    // window merge of the hypotheses of a pixel (see above)
-    constexpr int kRow = kMergeDepths ? Window<C>::kStrip : kStageRow;
+    static_assert(DPL == 1, "channels-last: one lane per (pixel, hypothesis); D = 4 with C <= 16 runs the split kernel below");
+    constexpr int kRow = kStageRow;
     __shared__ __attribute__((aligned(16))) float stage[DEFER ? 1 : kBlock / kWave][DEFER ? 1 : kWave][kRow];   // wave-private strips
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     if (tile >= dm.ntiles) return;
@@ -414,10 +391,6 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
         }
         sdot = group_sum<DL>(sdot);
         const int lane = threadIdx.x & 63;
-        [[maybe_unused]] bool have = false;
-        [[maybe_unused]] int xb = 0, yb = 0;
-        [[maybe_unused]] const int row_stride = dm.Ws * C;
-        if constexpr (kMergeDepths) window_zero<C>(stage[threadIdx.x >> 6][lane]);
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
             const float da = what[j] * (dw[j] - sdot) * inv_tc;
@@ -444,42 +417,9 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
                             make_float4(fmaf(gd[4 * g4 + 0][j], w, da) * (1.0f / CPG), fmaf(gd[4 * g4 + 1][j], w, da) * (1.0f / CPG),
                                         fmaf(gd[4 * g4 + 2][j], w, da) * (1.0f / CPG), fmaf(gd[4 * g4 + 3][j], w, da) * (1.0f / CPG));
                 }
-            } else if constexpr (kMergeDepths) {
-                float (*strip)[kRow] = stage[threadIdx.x >> 6];
-                float* __restrict__ mine = strip[lane];
-                const Taps& t = taps[j];
-                const bool active = live && t.mask != 0;
-                const int k = t.ix - xb;
-                const bool fits = have && t.iy == yb && k >= 0 && k <= 2;
-                const bool spill = active && have && !fits;
-                if (__any(spill)) {
-                    *reinterpret_cast<int2*>(&mine[Window<C>::kDwords]) = make_int2((yb * dm.Ws + xb) * C, spill ? 1 : 0);
-                    window_flush<C>(strip, lane, gsrcb, row_stride);
-                    if (spill) {
-                        window_zero<C>(mine);
-                        have = false;
-                    }
-                }
-                if (active) {
-                    if (!have) {
-                        // leave room in the direction the later hypotheses move along the epipolar line
-                        const bool leftward = taps[DPL - 1].ix < taps[0].ix;
-                        constexpr int A = Window<C>::kAlign;          // 2 (C=8) or 1 (C=16), a power of two
-                        // window = pixels xb..xb+3, xb line-aligned; it must contain t.ix and t.ix+1
-                        xb = leftward ? (((t.ix + 2 + (A - 1)) & ~(A - 1)) - 4) : (t.ix & ~(A - 1));
-                        yb = t.iy;
-                        have = true;
-                    }
-                    window_add<C>(mine, t.ix - xb, t, dwarp);
-                }
             } else {
                 dense_scatter<C>(stage[threadIdx.x >> 6], lane, taps[j], dwarp, gsrcb, live);
             }
-        }
-        if constexpr (kMergeDepths) {
-            float (*strip)[kRow] = stage[threadIdx.x >> 6];
-            *reinterpret_cast<int2*>(&strip[lane][Window<C>::kDwords]) = make_int2((yb * dm.Ws + xb) * C, have ? 1 : 0);
-            window_flush<C>(strip, lane, gsrcb, row_stride);
         }
     }
     float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C);
@@ -507,7 +447,7 @@ template <int C>
 constexpr int kSplitLanes = (C == 16) ? 4 : 2;    // C = 16: four lanes per pixel (4 channels = one float4 per tap and lane)
 
 template <int C, int G, int D, int HS>           // HS = lanes per pixel (2 or 4)
-__global__ void __launch_bounds__(kBlock, 2)      // 70 KB of LDS admits two workgroups per CU: keep the registers there too
+__global__ void __launch_bounds__(kBlock, 2)      // <= 36 KB of LDS per workgroup (HS = 4: 18 KB): registers decide, keep >= 2 workgroups per CU
 cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* __restrict__ vol,
                                   const float* __restrict__ wsum, const float* __restrict__ ref, SrcPtrs srcs,
                                   const float* __restrict__ pose, const float* __restrict__ hypo,
@@ -712,10 +652,14 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
             return launch_status();
         }
     }
-    if (layout == MVSTER_LAYOUT_NHWC)
-        hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
-                           ref, srcs, pose, hypo, gref, gsrcs, dm, static_cast<float*>(nullptr));
-    else
+    if (layout == MVSTER_LAYOUT_NHWC) {
+        // DPL > 1 is only dispatched for D = 4, C <= 16, which returned into the split kernel above
+        if constexpr (DPL == 1)
+            hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol,
+                               wsum, ref, srcs, pose, hypo, gref, gsrcs, dm, static_cast<float*>(nullptr));
+        else
+            return MVSTER_ERR_UNSUPPORTED;
+    } else
         hipLaunchKernelGGL((cost_volume_bwd_kernel<CPG, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol, wsum, ref,
                            srcs, pose, hypo, gref, gsrcs, dm);
     return launch_status();
@@ -728,6 +672,36 @@ extern "C" long long mvster_cost_volume_bwd_workspace(int S, int B, int C, int G
     if (S <= 0 || B <= 0 || G <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     if (!tile_scatter_applies(C, G, D, layout)) return 0;
     return (long long)B * S * H * W * D * G;
+}
+
+extern "C" int mvster_cost_volume_bwd_route(int S, int B, int C, int G, int D, int H, int W, int layout,
+                                            long long workspace_floats) {
+    return mvster::pick_bwd_route(S, B, C, G, D, H, W, layout, workspace_floats);
+}
+
+extern "C" int mvster_cost_volume_bwd_route_name(int route, int C, int G, int D, char* buf, int cap) {
+    char tmp[96];
+    int n = 0;
+    switch (route) {
+        case MVSTER_BWD_ROUTE_PLANAR: {
+            const bool wide = D == 4 && C <= mvster::kMaxWideChannels;      // only when pick_pixel_per_lane() held
+            n = snprintf(tmp, sizeof tmp, "cost_volume_bwd_kernel<%d, %d, %d, %s>", G ? C / G : 0, G, D, wide ? "1|4" : "1");
+            break;
+        }
+        case MVSTER_BWD_ROUTE_DENSE:
+            n = snprintf(tmp, sizeof tmp, "cost_volume_bwd_nhwc_kernel<%d, %d, %d, 1, false>", C, G, D);
+            break;
+        case MVSTER_BWD_ROUTE_SPLIT_WINDOW:
+            n = snprintf(tmp, sizeof tmp, "cost_volume_bwd_nhwc_split_kernel<%d, %d, 4, %d>", C, G, C == 16 ? 4 : 2);
+            break;
+        case MVSTER_BWD_ROUTE_TILE_SCATTER:
+            n = snprintf(tmp, sizeof tmp, "tile_scatter_kernel<128, 8>");
+            break;
+        default:
+            tmp[0] = 0;
+    }
+    if (buf != nullptr && cap > 0) snprintf(buf, (size_t)cap, "%s", tmp);
+    return n;
 }
 
 extern "C" int mvster_cost_volume_bwd(const float* gvol, const float* vol, const float* wsum, const float* ref,

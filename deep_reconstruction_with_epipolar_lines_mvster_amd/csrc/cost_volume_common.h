@@ -53,6 +53,16 @@ inline bool tile_scatter_applies(int C, int G, int D, int layout) {
     return layout == MVSTER_LAYOUT_NHWC && D == 8 && (C == 16 || C == 32 || C == 64) && shape_instantiated(C, G, D);
 }
 
+// Which kernel family the backward entry point runs for a shape (mvster_cost_volume_bwd_route in mvster_hip.h).
+inline int pick_bwd_route(int S, int B, int C, int G, int D, int H, int W, int layout, long long workspace_floats) {
+    if (S <= 0 || B <= 0 || H <= 0 || W <= 0 || !shape_instantiated(C, G, D)) return MVSTER_BWD_ROUTE_NONE;
+    if (layout != MVSTER_LAYOUT_NHWC) return MVSTER_BWD_ROUTE_PLANAR;
+    if (tile_scatter_applies(C, G, D, layout) && workspace_floats >= (long long)B * S * H * W * D * G)
+        return MVSTER_BWD_ROUTE_TILE_SCATTER;
+    if (pick_pixel_per_lane(B, H * W, C, D)) return MVSTER_BWD_ROUTE_SPLIT_WINDOW;
+    return MVSTER_BWD_ROUTE_DENSE;
+}
+
 int launch_tile_scatter(const float* dcor, const float* ref, const float* pose, const float* hypo, const GradPtrs& gsrcs,
                         int B, int C, int G, int D, const VolumeDims& dm, hipStream_t st);
 

@@ -129,6 +129,20 @@ int mvster_cost_volume_bwd_ws(const float *gvol, const float *vol, const float *
                               int Hs, int Ws, float attn_temp, int layout, float *workspace,
                               long long workspace_floats, mvster_stream_t stream);
 
+/* Which kernel family mvster_cost_volume_bwd_ws runs for a shape and workspace size (so that tests and the
+ * benchmark can state -- and assert -- the route instead of mirroring the dispatch rules).
+ * mvster_cost_volume_bwd_route_name: the route's dominant kernel as rocprofv3 prints it, e.g.
+ * "cost_volume_bwd_nhwc_split_kernel<8, 4, 4, 2>"; writes at most `cap` bytes including the terminator and returns
+ * the length it wanted to write (0 for MVSTER_BWD_ROUTE_NONE). */
+#define MVSTER_BWD_ROUTE_NONE 0          /* shape not instantiated: the entry point returns MVSTER_ERR_UNSUPPORTED   */
+#define MVSTER_BWD_ROUTE_PLANAR 1        /* NCHW planes, tap-by-tap atomics                                           */
+#define MVSTER_BWD_ROUTE_DENSE 2         /* channels-last, one LDS-transposed dense atomic strip per hypothesis       */
+#define MVSTER_BWD_ROUTE_SPLIT_WINDOW 3  /* channels-last, D = 4, C <= 16: per-pixel hypothesis window, 2/4 lanes per pixel */
+#define MVSTER_BWD_ROUTE_TILE_SCATTER 4  /* channels-last, D = 8: coefficient kernel + tiled LDS write-combining scatter  */
+int mvster_cost_volume_bwd_route(int S, int B, int C, int G, int D, int H, int W, int layout,
+                                 long long workspace_floats);
+int mvster_cost_volume_bwd_route_name(int route, int C, int G, int D, char *buf, int cap);
+
 /* --------------------------------------------------------------------------------------------
  * A4  post-regnet half: softmax over depth, FIRST arg-max, depth gather, confidence, next range.
  * replaces: models/mvs4net_utils.py:1109-1113,1126-1138,1151-1156.

@@ -72,3 +72,71 @@ def test_algorithmic_bytes_match_survey_totals():
     fwd_eval = fwd + sum(4 * H * W for (H, W, *_rest) in bench.DTU_STAGES)
     assert abs(fwd_eval / 1e6 - 925.9) < 0.2
     assert abs(bwd / 1e6 - 1496.6) < 0.2
+
+
+RANK_PROGRAM = """
+import json, os, sys
+import torch
+import torch.distributed as dist
+dist.init_process_group(backend="gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+if "--fail-on-rank-1" in sys.argv and rank == 1:
+    sys.exit(3)
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+if rank == 0:
+    print(json.dumps({"world": world, "sum": float(t), "local_rank": os.environ["LOCAL_RANK"], "argv": sys.argv[1:]}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_self_launcher_starts_ranks_and_relays_rank0(tmp_path, capsys):
+    """`python bench.py --gpus N` without torch.distributed.run: the parent spawns N ranks with the rendezvous
+    environment, relays rank 0's JSON line and returns 0 (control path on CPU/gloo with a stand-in rank program)."""
+    import json
+    import bench
+    prog = tmp_path / "rank_program.py"
+    prog.write_text(RANK_PROGRAM)
+    rc = bench.launch_ranks(2, ["--gpus", "2", "--steps", "1"], timeout_s=120, program=str(prog))
+    out = capsys.readouterr().out
+    assert rc == 0
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"world": 2, "sum": 3.0, "local_rank": "0", "argv": ["--gpus", "2", "--steps", "1"]}
+
+
+def test_self_launcher_propagates_a_failing_rank(tmp_path):
+    import bench
+    prog = tmp_path / "rank_program.py"
+    prog.write_text(RANK_PROGRAM)
+    t0 = time.time()
+    rc = bench.launch_ranks(2, ["--fail-on-rank-1"], timeout_s=120, program=str(prog))
+    assert rc != 0                       # rank 1 died: the surviving rank is terminated, the parent reports failure
+    assert time.time() - t0 < 100
+
+
+def test_exchange_buckets_add_up_to_the_reference_parameter_count():
+    import bench
+    assert sum(bench.EXCHANGE_BUCKETS) == bench.DDP_GRAD_ELEMS == 1009119
+
+
+def test_pmc_traffic_goes_null_when_the_kernel_sources_changed(tmp_path):
+    """roofline.traffic is only reported while the committed PMC summary was measured on the kernel sources in the tree."""
+    import json
+    import bench
+    fp = bench.source_fingerprint()
+    doc = {"some_kernel<1>": {"hbm_bytes_per_launch": 123.0, "TCC_EA0_ATOMIC_sum_avg": 5.0}, "_meta": {"csrc_sha": fp}}
+    f = tmp_path / "r9_pmc.json"
+    f.write_text(json.dumps(doc))
+    traffic, src, entry, why = bench.pmc_traffic("some_kernel<1>", path=str(f))
+    assert traffic == 123.0 and why is None and entry["TCC_EA0_ATOMIC_sum_avg"] == 5.0
+    doc["_meta"]["csrc_sha"] = "0" * 16                       # the sources moved on
+    f.write_text(json.dumps(doc))
+    traffic, src, entry, why = bench.pmc_traffic("some_kernel<1>", path=str(f))
+    assert traffic is None and "stale" in why
+    del doc["_meta"]                                          # a summary without provenance is not trusted either
+    f.write_text(json.dumps(doc))
+    assert bench.pmc_traffic("some_kernel<1>", path=str(f))[0] is None
+    assert bench.pmc_traffic("other_kernel", path=str(f))[0] is None

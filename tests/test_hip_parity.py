@@ -401,6 +401,119 @@ def test_tiled_scatter_edge_cases_vs_oracle(dev, C, G, S, B, H, W, Hs, Ws):
         assert float(gf[S].grad.abs().max()) == 0.0
 
 
+# ------------------------------------------------------------------------------------------ B > 1 at full size
+def batched_dtu_inputs(stage, B, S=4, seed=300):
+    """B different reference views at a DTU stage shape: independent noise features and per-sample smooth hypotheses
+    with a per-pixel random offset (so the batch elements gather from different places)."""
+    H, W, C, G, D, scale = DTU_STAGES[stage]
+    parts = [dtu_inputs(H, W, C, D, scale, seed=seed + 17 * b + stage, S=S) for b in range(B)]
+    g = torch.Generator().manual_seed(seed + stage)
+    feats = [torch.cat([p[0][v] for p in parts], 0) for v in range(S + 1)]
+    hypo = torch.cat([p[2] for p in parts], 0)
+    jitter = 1.0 + 0.02 * (torch.rand(B, 1, H, W, generator=g) - 0.5) * torch.arange(1, B + 1).view(B, 1, 1, 1)
+    mats = parts[0][1].repeat(B, 1, 1, 1, 1)
+    mats[:, 1:, 0, :3, 3] *= (1.0 + 0.05 * torch.arange(B).view(B, 1, 1))         # per-sample baselines
+    return feats, mats, (hypo * jitter).contiguous()
+
+
+@pytest.mark.parametrize("stage", range(4))
+def test_dtu_stage_batch4_equals_four_single_runs(dev, stage):
+    """BASELINE config 3 (batch = 4, the benchmark's configuration) at the literal DTU stage shapes: the forward of a
+    B = 4 call is bit-identical to four B = 1 calls (blockIdx.y batch offsets), the gradients agree up to atomic
+    summation order, and the backward takes the route the benchmark takes."""
+    H, W, C, G, D, scale = DTU_STAGES[stage]
+    B, S = 4, 4
+    feats, mats, hypo = batched_dtu_inputs(stage, B, S)
+    gvol = torch.randn(B, G, D, H, W, generator=torch.Generator().manual_seed(11))
+    pose = mv.stage_poses(mats.to(dev))
+    fb = [f.to(dev).requires_grad_(True) for f in feats]
+    vol = mv.fused_cost_volume(fb, pose, hypo.to(dev), G, 2.0)
+    vol.backward(gvol.to(dev))
+    need = _lib.load().mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC)
+    rid, label, symbol = _lib.bwd_route(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC, need)
+    print("    [route] stage%d B=%d backward: %s (%s)" % (stage + 1, B, label, symbol))
+    assert label == ("tile_scatter" if D == 8 else "split_window")
+    for b in range(B):
+        f1 = [f[b:b + 1].to(dev).requires_grad_(True) for f in feats]
+        v1 = mv.fused_cost_volume(f1, pose[b:b + 1].contiguous(), hypo[b:b + 1].to(dev), G, 2.0)
+        assert torch.equal(v1[0], vol[b]), "stage%d: batch element %d of the B=4 forward differs from its B=1 run" % (stage + 1, b)
+        v1.backward(gvol[b:b + 1].to(dev))
+        for i in range(S + 1):
+            close(fb[i].grad[b:b + 1], f1[i].grad, 1e-4, 1e-7, "stage%d b%d grad feat%d (B=4 vs B=1)" % (stage + 1, b, i))
+
+
+def test_dtu_stage4_batch4_vs_oracle(dev):
+    """Stage 4 (1184 x 1600, C8 D4 G4, S=4) at B = 4 against the CPU oracle: fused volume and all feature gradients."""
+    H, W, C, G, D, scale = DTU_STAGES[3]
+    B, S = 4, 4
+    feats, mats, hypo = batched_dtu_inputs(3, B, S, seed=500)
+    gvol = torch.randn(B, G, D, H, W, generator=torch.Generator().manual_seed(12))
+    cf = [f.clone().requires_grad_(True) for f in feats]
+    want = orc.fuse_source_views(cf, mats, hypo, True, G, 2.0, True)
+    want.backward(gvol)
+    gf = [f.to(dev).requires_grad_(True) for f in feats]
+    vol = mv.fused_cost_volume(gf, mv.stage_poses(mats.to(dev)), hypo.to(dev), G, 2.0)
+    close(vol, want.detach(), 2e-5, 1e-6, "stage4 B=4 volume")
+    vol.backward(gvol.to(dev))
+    for i in range(S + 1):
+        close(gf[i].grad, cf[i].grad, 1e-4, 1e-7, "stage4 B=4 grad feat%d" % i)
+
+
+@pytest.mark.parametrize("G,H,W,coherent", [(4, 592, 800, True), (4, 591, 799, False), (8, 592, 800, False),
+                                            (8, 591, 799, True)])
+def test_stage3_lane_split_backward_full_size(dev, G, H, W, coherent):
+    """C = 16, D = 4 at B = 2 (>= 8192 pixel-waves): the backward the benchmark and real training batches run at stage 3
+    (four lanes per pixel in round 1) -- xor-shuffle group sums, window re-basing, the dead-lane tail of a ragged
+    H*W -- against the planar kernel family (tap-by-tap atomics) and the route actually taken is reported/asserted."""
+    C, D, B, S = 16, 4, 2, 3
+    parts = [dtu_inputs(H, W, C, D, 0.5, seed=700 + b + G, S=S) for b in range(B)]
+    feats = [torch.cat([p[0][v] for p in parts], 0) for v in range(S + 1)]
+    mats = parts[0][1].repeat(B, 1, 1, 1, 1)
+    hypo = torch.cat([p[2] for p in parts], 0)
+    if not coherent:
+        g = torch.Generator().manual_seed(G)
+        inv = 1 / 935.0 + (1 / 425.0 - 1 / 935.0) * torch.rand(B, 1, H, W, generator=g)
+        hypo = (1.0 / (inv + (torch.arange(D).view(1, D, 1, 1) - (D - 1) / 2) * (1 / 425.0 - 1 / 935.0) / 256)).contiguous()
+    need = _lib.load().mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC)
+    rid, label, symbol = _lib.bwd_route(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC, need)
+    print("    [route] C16 G%d %dx%d B=2 backward: %s (%s)" % (G, H, W, label, symbol))
+    assert label == "split_window" and symbol.startswith("cost_volume_bwd_nhwc_split_kernel<16, %d, 4, 4>" % G)
+    pose = mv.stage_poses(mats.to(dev))
+    gvol = torch.randn(B, G, D, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    grads = {}
+    for layout in ("nchw", "nhwc"):
+        fin = [f.to(dev).requires_grad_(True) for f in feats]
+        mv.fused_cost_volume(fin, pose, hypo.to(dev), G, 2.0, layout=layout).backward(gvol)
+        grads[layout] = [f.grad for f in fin]
+    for i in range(S + 1):
+        close(grads["nhwc"][i], grads["nchw"][i], 2e-5, 1e-7, "C16 G%d %s grad feat%d" % (G, "smooth" if coherent else "random", i))
+
+
+@pytest.mark.parametrize("C,G,zoom", [(32, 8, 0.25), (64, 8, 0.25), (16, 4, 0.25), (32, 8, 1.0)])
+def test_cross_pixel_merge_when_every_step_collides(dev, C, G, zoom):
+    """Worst case for the cross-pixel merge of the D = 8 backward: fronto-parallel hypotheses (identical depth over the
+    whole map) and a source camera zoomed out 4x, so that the footprints of a whole 8 x 8 reference block fall on 2-3
+    source pixels -- in the round-1 tiled scatter every step of every tile row has all four lane groups on the same
+    cache entries (serialised steps, intra-wave LDS ordering); any merge scheme sees maximal destination collisions.
+    Against the CPU oracle's autograd."""
+    D, B, S, H, W = 8, 2, 2, 40, 48
+    g = torch.Generator().manual_seed(int(C + 100 * zoom))
+    feats = [0.7 * torch.randn(B, C, H, W, generator=g) for _ in range(S + 1)]
+    mats = synth_views(B, S + 1, H, W, scale=W / 1600.0)
+    mats[:, 1:, 1, 0, 0] *= zoom                           # source focal length: ref px / zoom per source px
+    mats[:, 1:, 1, 1, 1] *= zoom
+    mats[:, :, 0, :2, 3] *= 0.1
+    hypo = (1.0 / (1 / 800.0 + torch.arange(D).view(1, D, 1, 1) * 6e-5)).expand(B, D, H, W).contiguous()
+    gw = torch.randn(B, G, D, H, W, generator=g)
+    cf = [f.clone().requires_grad_(True) for f in feats]
+    (orc.fuse_source_views(cf, mats, hypo, True, G, 2.0, True) * gw).sum().backward()
+    gf = [f.to(dev).requires_grad_(True) for f in feats]
+    vol = mv.fused_cost_volume(gf, mv.stage_poses(mats.to(dev)), hypo.to(dev), G, 2.0)
+    (vol * gw.to(dev)).sum().backward()
+    for i in range(S + 1):
+        close(gf[i].grad, cf[i].grad, 1e-4, 1e-7, "collision tile C%d zoom %.2f grad feat%d" % (C, zoom, i))
+
+
 def test_identical_views_reduce_to_single_view(dev):
     """Size-independent property at the full stage-4 shape: fusing S copies of one source view gives the
     single-view correlation (num/den = S w cor / (1e-8 + S w))."""
@@ -462,7 +575,7 @@ OTHER_CONFIG_STAGES = [
     ("plumbing-s1", 64, 80, 64, 8, 4, 3, True), ("plumbing-s2", 128, 160, 32, 8, 4, 3, True),
     ("plumbing-s3", 256, 320, 16, 4, 4, 3, True), ("plumbing-s4", 512, 640, 8, 4, 4, 3, True),
     ("hires-s1", 192, 256, 64, 8, 16, 9, True), ("hires-s2", 384, 512, 32, 8, 8, 9, True),
-    ("hires-s3", 768, 1024, 16, 4, 8, 9, False), ("hires-s4", 1536, 2048, 8, 4, 4, 9, False),
+    ("hires-s3", 768, 1024, 16, 4, 8, 9, True), ("hires-s4", 1536, 2048, 8, 4, 4, 9, True),
 ]
 
 
@@ -485,6 +598,13 @@ def test_other_baseline_config_stage_shapes(dev, name, H, W, C, G, D, S, with_ba
         (vol * gw.to(dev)).sum().backward()
         for i in (0, 1, S):
             close(gf[i].grad, cf[i].grad, 1e-4, 1e-7, name + " grad feat%d" % i)
+        if name.startswith("hires"):
+            # the channels-last scatter routes (tiled / window) against the planar family's tap-by-tap atomics
+            pf = [f.to(dev).requires_grad_(True) for f in feats]
+            pvol = mv.fused_cost_volume(pf, mv.stage_poses(mats.to(dev)), hypo.to(dev), G, 2.0, layout="nchw")
+            (pvol * gw.to(dev)).sum().backward()
+            for i in range(S + 1):
+                close(gf[i].grad, pf[i].grad, 2e-5, 1e-7, name + " grad feat%d vs planar route" % i)
 
 
 def _stage_vs_oracle(dev, feats, mats, hypo, G, training=False, tol=2e-5):

@@ -29,8 +29,19 @@ def main():
     ap.add_argument("--eval", action="store_true")
     ap.add_argument("--benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (slow MIOpen find)")
     ap.add_argument("--bn", default="hip", choices=["hip", "native", "miopen"])
+    ap.add_argument("--ddp", action="store_true",
+                    help="wrap the model in DistributedDataParallel over RCCL like train_mvs4.py:562-570 (one process per GPU; "
+                         "start with torch.distributed.run, or alone for a one-rank group)")
     args = ap.parse_args()
-    dev = torch.device("cuda:0")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if args.ddp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
+        dist.init_process_group(backend="nccl", init_method="env://", rank=int(os.environ.get("RANK", "0")),
+                                world_size=int(os.environ.get("WORLD_SIZE", "1")), device_id=dev)
     # the reference drivers set cudnn.benchmark = True (train_mvs4.py:16, test_mvs4.py:25); on ROCm that makes MIOpen run
     # its exhaustive find for every convolution configuration -- the first step then takes more than 7 minutes
     torch.backends.cudnn.benchmark = args.benchmark
@@ -43,6 +54,8 @@ def main():
                        group_cor_dim=[8, 8, 4, 4], inverse_depth=True, mono=True, attn_temp=2).to(dev)
     if args.channels_last:
         model.to_channels_last(True)
+    if args.ddp:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     imgs = [torch.rand(B, 3, H, W, device=dev) for _ in range(N)]
     proj = {}
@@ -75,6 +88,10 @@ def main():
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    if args.ddp:
+        import torch.distributed as dist
+        print("DDP over %s, %d rank(s)" % (dist.get_backend(), dist.get_world_size()), flush=True)
+        dist.destroy_process_group()
     print("e2e %s step (bn=%s): %dx%d, N=%d, B=%d, channels_last=%s: %.1f ms/step = %.2f ref-views/s, peak mem %.1f GB"
           % ("eval" if args.eval else "train", args.bn, W, H, N, B, args.channels_last, dt * 1e3, B / dt,
              torch.cuda.max_memory_allocated() / 1e9), flush=True)

@@ -40,6 +40,17 @@ def main():
             e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE_avg"] * 1024
             e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
         out[k] = e
+    # tie the summary to the kernel sources it was measured on: bench.py reports roofline.traffic only while they match
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    try:
+        head = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = ""
+    out["_meta"] = {"csrc_sha": bench.source_fingerprint(), "head_at_collection": head or os.environ.get("MVSTER_HEAD", "")}
     json.dump(out, open(args.out, "w"), indent=1, sort_keys=True)
     print("wrote", args.out, len(out), "kernels")
 
