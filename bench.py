@@ -166,8 +166,8 @@ def kernel_symbol(entry, B, C, G, D, H, W, S):
     """Name of the dominant gfx950 kernel an ABI entry point launches for this shape, as rocprofv3 prints it.  The
     backward's route comes from the library itself (mvster_cost_volume_bwd_route), not from a mirror of its rules."""
     if entry == "mvster_cost_volume_bwd":
-        need = _lib.load().mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC)
-        return _lib.bwd_route(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC, need)[2]
+        need = _lib.bwd_workspace(S, B, C, G, D, H, W, H, W, _lib.LAYOUT_NHWC)
+        return _lib.bwd_route(S, B, C, G, D, H, W, H, W, _lib.LAYOUT_NHWC, need)[2]
     if entry == "mvster_cost_volume_fwd":
         return "cost_volume_fwd_nhwc_kernel<%d, %d, %d, 1>" % (C, G, D)
     return entry.replace("mvster_", "") + "_kernel"

@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmvster_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -30,8 +30,9 @@ PROTOTYPES = {
                                _vp],
     "mvster_cost_volume_bwd_ws": [_vp, _vp, _vp, _vp, _vpp, _i, _vp, _vp, _vp, _vpp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i,
                                   _vp, _ll, _vp],
-    "mvster_cost_volume_bwd_workspace": [_i, _i, _i, _i, _i, _i, _i, _i],
-    "mvster_cost_volume_bwd_route": [_i, _i, _i, _i, _i, _i, _i, _i, _ll],
+    "mvster_cost_volume_bwd_workspace": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "mvster_cost_volume_bwd_route_workspace": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "mvster_cost_volume_bwd_route": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _ll],
     "mvster_cost_volume_bwd_route_name": [_i, _i, _i, _i, ctypes.c_char_p, _i],
     "mvster_depth_regress_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "mvster_softmax_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -46,7 +47,7 @@ PROTOTYPES = {
     "mvster_schedule_inverse_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
 }
 
-RESTYPES = {"mvster_cost_volume_bwd_workspace": _ll}      # everything else returns the int status
+RESTYPES = {"mvster_cost_volume_bwd_workspace": _ll, "mvster_cost_volume_bwd_route_workspace": _ll}      # everything else returns the int status
 
 MVSTER_OK = 0
 LAYOUT_NCHW = 0
@@ -116,13 +117,24 @@ def try_call(name, *args):
     return True
 
 
-BWD_ROUTES = {0: "none", 1: "planar", 2: "dense", 3: "split_window", 4: "tile_scatter"}
+BWD_ROUTES = {0: "none", 1: "planar", 2: "dense", 3: "split_window", 4: "tile_scatter", 5: "binned"}
 
 
-def bwd_route(S, B, C, G, D, H, W, layout, workspace_floats):
+ROUTE_IDS = {v: k for k, v in BWD_ROUTES.items()}
+
+
+def bwd_workspace(S, B, C, G, D, H, W, Hs, Ws, layout, route=None):
+    """4-byte words of scratch the recommended backward route of this shape wants (0: none); with ``route`` (a label of
+    BWD_ROUTES) the words that route needs, -1 when it does not exist for the shape."""
+    if route is None:
+        return load().mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, Hs, Ws, layout)
+    return load().mvster_cost_volume_bwd_route_workspace(ROUTE_IDS[route], S, B, C, G, D, H, W, Hs, Ws, layout)
+
+
+def bwd_route(S, B, C, G, D, H, W, Hs, Ws, layout, workspace_floats):
     """(route id, route label, dominant kernel symbol as rocprofv3 prints it) the backward entry point picks."""
     lib = load()
-    rid = lib.mvster_cost_volume_bwd_route(S, B, C, G, D, H, W, layout, workspace_floats)
+    rid = lib.mvster_cost_volume_bwd_route(S, B, C, G, D, H, W, Hs, Ws, layout, workspace_floats)
     buf = ctypes.create_string_buffer(128)
     lib.mvster_cost_volume_bwd_route_name(rid, C, G, D, buf, len(buf))
     return rid, BWD_ROUTES.get(rid, "route%d" % rid), buf.value.decode()

@@ -1,0 +1,644 @@
+// Atomics-free scatter of the source-feature gradient: second half of the "binned" backward route.
+//
+// replaces: the autograd backward of F.grid_sample w.r.t. the source feature inside homo_warping
+// (models/mvs4net_utils.py:59), summed over hypotheses and reference pixels, for the channels-last layout.
+//
+// Why.  Global float atomics execute at the memory side at ~1.3 TB/s of added bytes (~20 G 64-byte requests/s,
+// MI355X_MICROARCH.md "Global float atomics"); every scatter route built on them is pinned to that rate however the taps
+// are merged first (cost_volume_bwd.hip, cost_volume_scatter.hip).  Here the destination gets OWNERS instead: the source
+// map of every (batch, view) is cut into tiles; every (pixel, hypothesis) sample is listed in the tiles its 2x2 footprint
+// touches (a counting sort keyed by tile: count -> scan -> fill); one workgroup per tile then sorts its list once more in
+// LDS by the source pixel of the sample's upper-left tap, and every lane -- the owner of one such pixel -- walks its own
+// samples and sums their four taps in registers.  The four tap images are folded into the tile (four conflict-free
+// passes over an LDS image) and the tile is written once with plain 16-byte stores.  No global float atomic, no memset of
+// the gradient maps, a cost that does not depend on how coherent the depth maps are.
+//
+// Kernels (all launched by launch_binned_scatter on the caller's stream):
+//   bin_items_kernel<false, D>  a workgroup = an 8x8 / 8x4 / 4x4 block of reference pixels x D hypotheses: project, count
+//                               the tiles touched per view in an LDS hash table, one global int atomic per distinct tile
+//   bin_scan_partials_kernel, bin_scan_apply_kernel   exclusive scan of the tile counts
+//   bin_items_kernel<true, D>   same projection; ranks inside the workgroup from the LDS table, one RETURNING global
+//                               atomic per distinct tile claims the slots, items written
+//   tile_owner_kernel<C,G,D>    one workgroup per tile as described above (C = 8: tile_owner_c8_kernel<G,D>)
+// The per-(view, pixel, hypothesis) group coefficients come from cost_volume_bwd_nhwc_kernel<..., DEFER = true>
+// (cost_volume_bwd.hip): tap gradient = coef[group(c)] * ref[c] * bilinear weight.
+#include "cost_volume_common.h"
+
+namespace mvster {
+
+// ------------------------------------------------------------------------------------------------ counting sort by tile
+struct BinArgs {
+    const float* pose;      // [B,S,12]
+    const float* hypo;      // [B,D,HW]
+    VolumeDims dm;
+    BinGrid bg;
+    int tiles_per_view, blocks_x;
+};
+
+// Tiles (within one (batch, view) plane) that receive a non-zero tap of one sample: id[k] is the tile of tap k and
+// emit[k] tells whether tap k is the first tap with a non-zero weight in that tile.  At most four tiles.
+__device__ __forceinline__ void footprint_tiles(const Taps& t, const BinGrid& bg, int (&id)[4], bool (&emit)[4]) {
+    bool nz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        nz[k] = masked_weight(t, k) != 0.0f;                       // in-map taps only: coordinates are >= 0 there
+        id[k] = ((t.iy + (k >> 1)) >> bg.lh) * bg.tiles_x + ((t.ix + (k & 1)) >> bg.lw);
+    }
+    emit[0] = nz[0];
+    emit[1] = nz[1] && !(nz[0] && id[0] == id[1]);
+    emit[2] = nz[2] && !(nz[0] && id[0] == id[2]) && !(nz[1] && id[1] == id[2]);
+    emit[3] = nz[3] && !(nz[0] && id[0] == id[3]) && !(nz[1] && id[1] == id[3]) && !(nz[2] && id[2] == id[3]);
+}
+
+constexpr int kViewBatch = 4;        // views whose tables are live together (their global atomics are in flight together)
+constexpr int kTableLog = 8;         // LDS hash table entries per view: 256 lanes x <= 4 tiles rarely exceed a few dozen keys
+constexpr int kTable = 1 << kTableLog;
+constexpr int kMaxProbes = 24;
+
+// A workgroup's samples of one view touch a handful of tiles.  Counting them one global atomic per lane runs at the
+// per-lane atomic rate (557 M adds = 8.6 ms at DTU stage 4, measured); aggregated per workgroup it is one request per
+// distinct tile.  table: open addressing, linear probing; a sample that finds no entry within kMaxProbes goes to memory
+// on its own (correct, just slow).
+// FILL = false: counters[tile] += n.  FILL = true: counters is the cursor array (starts at the tile's offset); the value
+// returned by the add is the first position of the workgroup's samples of that tile.
+template <bool FILL, int D>
+__global__ void __launch_bounds__(kBlock)
+bin_items_kernel(BinArgs a, int* __restrict__ counters, int* __restrict__ items) {
+    constexpr int PXB = kBlock / D;                                // reference pixels per workgroup
+    constexpr int BWP = 8, BHP = PXB / BWP;                        // as an 8 x (8 | 4 | 2) block
+    __shared__ int keys[kViewBatch][kTable];
+    __shared__ int cnts[kViewBatch][kTable];
+    [[maybe_unused]] __shared__ int bases[kViewBatch][kTable];
+    const VolumeDims& dm = a.dm;
+    const int HW = dm.H * dm.W;
+    const int b = blockIdx.y;
+    const int by = blockIdx.x / a.blocks_x, bx = blockIdx.x - by * a.blocks_x;
+    const int d = threadIdx.x % D, q = threadIdx.x / D;
+    const int xr = bx * BWP + q % BWP, yr = by * BHP + q / BWP;
+    const bool live = xr < dm.W && yr < dm.H;
+    const int x = min(xr, dm.W - 1), y = min(yr, dm.H - 1);
+    const int p = y * dm.W + x;
+    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+    const float hyp = a.hypo[((size_t)b * D + d) * HW + p];
+    const int item = p * D + d;
+
+    for (int s0 = 0; s0 < dm.S; s0 += kViewBatch) {
+        for (int e = threadIdx.x; e < kViewBatch * kTable; e += kBlock) {
+            (&keys[0][0])[e] = -1;
+            (&cnts[0][0])[e] = 0;
+        }
+        __syncthreads();
+        int where[kViewBatch][4];        // table entry of (view, tap); -1: nothing to emit; -2: table full, go direct
+        int rank[kViewBatch][4];
+        int tile[kViewBatch][4];
+#pragma unroll
+        for (int v = 0; v < kViewBatch; ++v) {
+            const int s = s0 + v;
+            const bool on = live && s < dm.S;
+            const Pose qv = load_pose(a.pose + ((size_t)b * dm.S + min(s, dm.S - 1)) * 12);
+            const Taps t = project_taps(qv, rotate_pixel(qv, (float)x, (float)y), hyp, dm.Hs, dm.Ws, half_w, half_h);
+            bool emit[4];
+            footprint_tiles(t, a.bg, tile[v], emit);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                where[v][k] = -1;
+                rank[v][k] = 0;
+                if (on && emit[k]) {
+                    unsigned h = ((unsigned)tile[v][k] * 0x9E3779B1u) >> (32 - kTableLog);
+                    int found = -2;
+                    for (int probe = 0; probe < kMaxProbes; ++probe) {
+                        const int old = atomicCAS(&keys[v][h], -1, tile[v][k]);
+                        if (old == -1 || old == tile[v][k]) {
+                            found = (int)h;
+                            break;
+                        }
+                        h = (h + 1) & (kTable - 1);
+                    }
+                    where[v][k] = found;
+                    if (found >= 0) rank[v][k] = atomicAdd(&cnts[v][found], 1);
+                }
+            }
+        }
+        __syncthreads();
+        // one global atomic per distinct (view, tile) of the workgroup
+        for (int e = threadIdx.x; e < kViewBatch * kTable; e += kBlock) {
+            const int n = (&cnts[0][0])[e];
+            if (n > 0) {
+                const int v = e >> kTableLog;
+                int* __restrict__ c = counters + ((size_t)b * dm.S + (s0 + v)) * a.tiles_per_view + (&keys[0][0])[e];
+                if constexpr (FILL) (&bases[0][0])[e] = atomicAdd(c, n);
+                else atomicAdd(c, n);
+            }
+        }
+        if constexpr (FILL) __syncthreads();
+#pragma unroll
+        for (int v = 0; v < kViewBatch; ++v) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (where[v][k] == -2) {                           // table full: on its own
+                    int* __restrict__ c = counters + ((size_t)b * dm.S + (s0 + v)) * a.tiles_per_view + tile[v][k];
+                    if constexpr (FILL) items[atomicAdd(c, 1)] = item;
+                    else atomicAdd(c, 1);
+                } else if (FILL && where[v][k] >= 0) {
+                    items[bases[v][where[v][k]] + rank[v][k]] = item;
+                }
+            }
+        }
+        __syncthreads();                                           // tables are cleared again next round
+    }
+}
+
+// exclusive scan of counts[n] in two launches: per-block sums, then every block adds the sums of the blocks before it
+constexpr int kScanBlock = 1024;
+
+__device__ __forceinline__ int block_sum(int v, int* wave_tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) v += __shfl_xor(v, m, kWave);
+    if (lane == 0) wave_tot[wave] = v;
+    __syncthreads();
+    int tot = 0;
+    for (int w = 0; w < kScanBlock / kWave; ++w) tot += wave_tot[w];
+    __syncthreads();
+    return tot;
+}
+
+__global__ void __launch_bounds__(kScanBlock)
+bin_scan_partials_kernel(const int* __restrict__ counts, int* __restrict__ partials, int n) {
+    __shared__ int wave_tot[kScanBlock / kWave];
+    const int i = blockIdx.x * kScanBlock + threadIdx.x;
+    const int tot = block_sum(i < n ? counts[i] : 0, wave_tot);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// offsets[i] = sum of counts[0..i), offsets[n] = total; cursor[i] = offsets[i] (consumed by the fill pass)
+__global__ void __launch_bounds__(kScanBlock)
+bin_scan_apply_kernel(const int* __restrict__ counts, const int* __restrict__ partials, int* __restrict__ offsets,
+                      int* __restrict__ cursor, int n) {
+    __shared__ int wave_tot[kScanBlock / kWave];
+    int before = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += kScanBlock) before += partials[j];
+    const int base = block_sum(before, wave_tot);
+    const int i = blockIdx.x * kScanBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mine = i < n ? counts[i] : 0;
+    int incl = mine;
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) {
+        const int up = __shfl_up(incl, m, kWave);
+        if (lane >= m) incl += up;
+    }
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+    const int excl = base + wbase + incl - mine;
+    if (i < n) {
+        offsets[i] = excl;
+        cursor[i] = excl;
+    }
+    if (i == n - 1) offsets[n] = excl + mine;
+}
+
+// ------------------------------------------------------------------------------------------------ one workgroup per tile
+struct OwnerArgs {
+    const float* dcor;      // [B,S,HW,D,G]
+    const float* ref;       // [B,HW,C]
+    const float* pose;
+    const float* hypo;
+    const int* offsets;     // [nbins + 1]
+    const int* items;
+    GradPtrs gsrcs;
+    VolumeDims dm;
+    BinGrid bg;
+    int tiles_per_view, nbins;
+};
+
+template <int C>
+struct OwnerTile {
+    static constexpr int TW = 1 << BinTile<C>::kLw, TH = 1 << BinTile<C>::kLh;
+    static constexpr int BW = TW + 1, BH = TH + 1;                 // source pixels that can hold the upper-left tap of a sample
+    static constexpr int NCELL = BW * BH;                          // touching the tile: one column / row of halo
+    static constexpr int NT = ((NCELL + kWave - 1) / kWave) * kWave;   // one lane per such pixel: 192 / 192 / 192 / 128
+    static constexpr int KPT = C == 8 ? 4 : 8;                     // samples a lane sorts per chunk
+    static constexpr int CHUNK = NT * KPT;                         // 768 (48 B each in LDS) / 1536 / 1536 / 1024 samples (16 B each)
+};
+
+struct __attribute__((aligned(16))) SampleRec {
+    int id;                 // p * D + d
+    int mask;               // in-map bits of the four taps
+    float fx, fy;           // fractional sample position
+};
+
+template <int C, int G, int D>
+__global__ void __launch_bounds__(OwnerTile<C>::NT)
+tile_owner_kernel(OwnerArgs a) {
+    using T = OwnerTile<C>;
+    constexpr int TW = T::TW, TH = T::TH, BW = T::BW, NCELL = T::NCELL, NT = T::NT, KPT = T::KPT, CHUNK = T::CHUNK;
+    constexpr int LW = BinTile<C>::kLw, LH = BinTile<C>::kLh;
+    constexpr int CPG = C / G;
+    constexpr int CH = 8;                                          // channels per walk: 4 taps x 8 accumulators per lane
+    constexpr int GPC = CH / CPG > 0 ? CH / CPG : 1;               // coefficient groups a channel chunk spans
+    constexpr int PF = 2;                                          // samples in flight per owner
+    static_assert(CPG <= CH ? CH % CPG == 0 : CPG % CH == 0, "a channel chunk holds whole groups or lies inside one");
+    __shared__ SampleRec sorted[CHUNK];
+    __shared__ int cnt[NT], start[NT];
+    __shared__ __attribute__((aligned(16))) float out[TH * TW * C];
+
+    const int bin = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    if (bin >= a.nbins) return;
+    const VolumeDims& dm = a.dm;
+    const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
+    const int tv = bin % a.tiles_per_view, bs = bin / a.tiles_per_view;
+    const int s = bs % dm.S, b = bs / dm.S;
+    const int ty = tv / a.bg.tiles_x, tx = tv - ty * a.bg.tiles_x;
+    const int x0 = tx << LW, y0 = ty << LH;
+    const int tid = threadIdx.x;
+    // this lane owns the samples whose upper-left tap is source pixel (x0 - 1 + cbx, y0 - 1 + cby)
+    const int cby = tid / BW, cbx = tid - cby * BW;
+    const bool owner = tid < NCELL;
+
+    for (int i = tid; i < TH * TW * C; i += NT) out[i] = 0.0f;
+
+    const int beg = a.offsets[bin], n = a.offsets[bin + 1] - beg;
+    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+    const Pose q = load_pose(a.pose + ((size_t)b * dm.S + s) * 12);
+    const float* __restrict__ hypo = a.hypo + (size_t)b * D * HW;
+    const float* __restrict__ dcor = a.dcor + ((size_t)b * dm.S + s) * HW * D * G;
+    const float* __restrict__ ref = a.ref + (size_t)b * HW * C;
+
+    for (int c0 = 0; c0 < n; c0 += CHUNK) {
+        const int m = min(CHUNK, n - c0);
+        cnt[tid] = 0;
+        __syncthreads();                                           // also: the previous chunk's walk is over, `out` is zeroed
+        // ---- sort the chunk by owning pixel: count ...
+        SampleRec rec[KPT];
+        int cell[KPT], slot[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int i = tid + j * NT;
+            cell[j] = -1;
+            if (i < m) {
+                const int id = a.items[beg + c0 + i];
+                const int p = id / D, d = id - p * D;
+                const int y = p / dm.W, x = p - y * dm.W;
+                const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hypo[(size_t)d * HW + p], dm.Hs, dm.Ws,
+                                            half_w, half_h);
+                const int cx = t.ix - x0 + 1, cy = t.iy - y0 + 1;
+                rec[j].id = id;
+                rec[j].mask = t.mask;
+                rec[j].fx = t.fx;
+                rec[j].fy = t.fy;
+                if ((unsigned)cx < (unsigned)BW && (unsigned)cy < (unsigned)T::BH) {     // always, for a sample of this tile
+                    cell[j] = cy * BW + cx;
+                    slot[j] = atomicAdd(&cnt[cell[j]], 1);
+                }
+            }
+        }
+        __syncthreads();
+        // ... scan (first wave; NT / 64 consecutive counters per lane) ...
+        if (tid < kWave) {
+            constexpr int R = NT / kWave;
+            int v[R], tot = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                v[r] = cnt[tid * R + r];
+                tot += v[r];
+            }
+            int incl = tot;
+#pragma unroll
+            for (int mm = 1; mm < kWave; mm <<= 1) {
+                const int up = __shfl_up(incl, mm, kWave);
+                if (tid >= mm) incl += up;
+            }
+            int run = incl - tot;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                start[tid * R + r] = run;
+                run += v[r];
+            }
+        }
+        __syncthreads();
+        // ... place
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if (cell[j] >= 0) sorted[start[cell[j]] + slot[j]] = rec[j];
+        __syncthreads();
+
+        // ---- every owner walks its samples, eight channels at a time ---------------------------------------------------
+        const int mine = owner ? cnt[tid] : 0, first = owner ? start[tid] : 0;
+        for (int ch = 0; ch < C; ch += CH) {
+            float acc[4][CH];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) acc[k][c] = 0.0f;
+            // The samples of one owner are walked PF at a time with all their loads issued together: the walk is bound by
+            // the latency of these gathers (coefficients and reference features come from HBM / L2), not by arithmetic.
+            for (int k = 0; k < mine; k += PF) {
+                SampleRec r[PF];
+                float4 r0[PF], r1[PF];
+                float cf[PF][GPC];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    r[u] = sorted[first + min(k + u, mine - 1)];
+                    if (k + u >= mine) r[u].mask = 0;              // past the end: a repeat of the last sample, weightless
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int pj = r[u].id / D;
+                    const float4* __restrict__ rp = reinterpret_cast<const float4*>(ref + (size_t)pj * C + ch);
+                    r0[u] = rp[0];
+                    r1[u] = rp[1];
+                    const float* __restrict__ cp = dcor + (size_t)r[u].id * G + ch / CPG;
+                    if constexpr (GPC == 8) {
+                        const float4 a0 = reinterpret_cast<const float4*>(cp)[0], a1 = reinterpret_cast<const float4*>(cp)[1];
+                        cf[u][0] = a0.x; cf[u][1] = a0.y; cf[u][2] = a0.z; cf[u][3] = a0.w;
+                        cf[u][4] = a1.x; cf[u][5] = a1.y; cf[u][6] = a1.z; cf[u][7] = a1.w;
+                    } else if constexpr (GPC == 4) {
+                        const float4 a0 = reinterpret_cast<const float4*>(cp)[0];
+                        cf[u][0] = a0.x; cf[u][1] = a0.y; cf[u][2] = a0.z; cf[u][3] = a0.w;
+                    } else if constexpr (GPC == 2) {
+                        const float2 a0 = reinterpret_cast<const float2*>(cp)[0];
+                        cf[u][0] = a0.x; cf[u][1] = a0.y;
+                    } else {
+                        cf[u][0] = cp[0];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const float rv[CH] = {r0[u].x, r0[u].y, r0[u].z, r0[u].w, r1[u].x, r1[u].y, r1[u].z, r1[u].w};
+                    float w[4];
+                    weights_from_fraction(r[u].fx, r[u].fy, r[u].mask, w);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const float dwarp = cf[u][CPG <= CH ? c / CPG : 0] * rv[c];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) acc[kk][c] = fmaf(dwarp, w[kk], acc[kk][c]);
+                    }
+                }
+            }
+            // ---- fold the four tap images into the tile: within a pass every lane targets its own pixel ----------------
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int lx = cbx - 1 + (kk & 1), ly = cby - 1 + (kk >> 1);
+                if (owner && (unsigned)lx < (unsigned)TW && (unsigned)ly < (unsigned)TH) {
+                    float4* __restrict__ o = reinterpret_cast<float4*>(&out[(ly * TW + lx) * C + ch]);
+                    float4 u = o[0], v = o[1];
+                    u.x += acc[kk][0]; u.y += acc[kk][1]; u.z += acc[kk][2]; u.w += acc[kk][3];
+                    v.x += acc[kk][4]; v.y += acc[kk][5]; v.z += acc[kk][6]; v.w += acc[kk][7];
+                    o[0] = u;
+                    o[1] = v;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- the tile's only trip to memory: plain 16-byte stores, every pixel of the tile (zeros included) -------------
+    float* __restrict__ gsrc = a.gsrcs.p[s] + (size_t)b * HWs * C;
+    for (int e = tid; e < TH * TW * C / 4; e += NT) {
+        const int cellp = (4 * e) / C, chn = (4 * e) % C;
+        const int lx = cellp & (TW - 1), ly = cellp >> LW;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < dm.Ws && gy < dm.Hs)
+            *reinterpret_cast<float4*>(gsrc + ((size_t)gy * dm.Ws + gx) * C + chn) = *reinterpret_cast<const float4*>(&out[cellp * C + chn]);
+    }
+}
+
+// ---- C = 8: the same ownership scheme with everything a sample contributes staged in LDS ---------------------------------
+// At eight channels the stage has the most samples (DTU stage 4: 139 M per backward) and the least arithmetic per
+// sample; walking them with one gather per step (kernel above) is bound by the latency of those gathers (3.9 ms).
+// Here the sorting pass -- one lane per SAMPLE, all lanes busy, neighbouring lanes = the hypotheses of one pixel, so
+// their coefficient and reference loads share lines -- also fetches the coefficients and the reference feature and
+// leaves the finished per-channel gradient coef[group(c)] * ref[c] in the sample's LDS record (48 bytes).  The owners'
+// walk then touches LDS only.
+struct __attribute__((aligned(16))) StagedRec {
+    int mask;               // in-map bits of the four taps
+    float fx, fy;           // fractional sample position
+    int pad;
+    float dw[8];            // coef[group(c)] * ref[c]
+};
+
+template <int G, int D>
+__global__ void __launch_bounds__(OwnerTile<8>::NT)
+tile_owner_c8_kernel(OwnerArgs a) {
+    constexpr int C = 8;
+    using T = OwnerTile<C>;
+    constexpr int TW = T::TW, TH = T::TH, BW = T::BW, NCELL = T::NCELL, NT = T::NT, KPT = T::KPT, CHUNK = T::CHUNK;
+    constexpr int LW = BinTile<C>::kLw, LH = BinTile<C>::kLh;
+    constexpr int CPG = C / G;
+    __shared__ StagedRec sorted[CHUNK];
+    __shared__ int cnt[NT], start[NT];
+    __shared__ __attribute__((aligned(16))) float out[TH * TW * C];
+
+    const int bin = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    if (bin >= a.nbins) return;
+    const VolumeDims& dm = a.dm;
+    const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
+    const int tv = bin % a.tiles_per_view, bs = bin / a.tiles_per_view;
+    const int s = bs % dm.S, b = bs / dm.S;
+    const int ty = tv / a.bg.tiles_x, tx = tv - ty * a.bg.tiles_x;
+    const int x0 = tx << LW, y0 = ty << LH;
+    const int tid = threadIdx.x;
+    const int cby = tid / BW, cbx = tid - cby * BW;
+    const bool owner = tid < NCELL;
+
+    for (int i = tid; i < TH * TW * C; i += NT) out[i] = 0.0f;
+
+    const int beg = a.offsets[bin], n = a.offsets[bin + 1] - beg;
+    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+    const Pose q = load_pose(a.pose + ((size_t)b * dm.S + s) * 12);
+    const float* __restrict__ hypo = a.hypo + (size_t)b * D * HW;
+    const float* __restrict__ dcor = a.dcor + ((size_t)b * dm.S + s) * HW * D * G;
+    const float* __restrict__ ref = a.ref + (size_t)b * HW * C;
+
+    float acc[4][C];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[k][c] = 0.0f;
+
+    for (int c0 = 0; c0 < n; c0 += CHUNK) {
+        const int m = min(CHUNK, n - c0);
+        cnt[tid] = 0;
+        __syncthreads();
+        // ---- fetch: ids first, then everything that depends on them, all in flight together ----------------------------
+        int id[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int i = tid + j * NT;
+            id[j] = i < m ? a.items[beg + c0 + i] : -1;
+        }
+        float hyp[KPT], cf[KPT][G];
+        float4 r0[KPT], r1[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int idj = max(id[j], 0);
+            const int p = idj / D, d = idj - p * D;
+            hyp[j] = hypo[(size_t)d * HW + p];
+            const float4* __restrict__ cp = reinterpret_cast<const float4*>(dcor + (size_t)idj * G);
+            const float4 a0 = cp[0];
+            cf[j][0] = a0.x; cf[j][1] = a0.y; cf[j][2] = a0.z; cf[j][3] = a0.w;
+            if constexpr (G == 8) {
+                const float4 a1 = cp[1];
+                cf[j][4] = a1.x; cf[j][5] = a1.y; cf[j][6] = a1.z; cf[j][7] = a1.w;
+            }
+            const float4* __restrict__ rp = reinterpret_cast<const float4*>(ref + (size_t)p * C);
+            r0[j] = rp[0];
+            r1[j] = rp[1];
+        }
+        // ---- project, count per owner ----------------------------------------------------------------------------------
+        StagedRec rec[KPT];
+        int cell[KPT], slot[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            cell[j] = -1;
+            if (id[j] >= 0) {
+                const int p = id[j] / D;
+                const int y = p / dm.W, x = p - y * dm.W;
+                const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hyp[j], dm.Hs, dm.Ws, half_w, half_h);
+                const int cx = t.ix - x0 + 1, cy = t.iy - y0 + 1;
+                rec[j].mask = t.mask;
+                rec[j].fx = t.fx;
+                rec[j].fy = t.fy;
+                rec[j].pad = 0;
+                const float rv[C] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w, r1[j].x, r1[j].y, r1[j].z, r1[j].w};
+#pragma unroll
+                for (int c = 0; c < C; ++c) rec[j].dw[c] = cf[j][c / CPG] * rv[c];
+                if ((unsigned)cx < (unsigned)BW && (unsigned)cy < (unsigned)T::BH) {
+                    cell[j] = cy * BW + cx;
+                    slot[j] = atomicAdd(&cnt[cell[j]], 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < kWave) {
+            constexpr int R = NT / kWave;
+            int v[R], tot = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                v[r] = cnt[tid * R + r];
+                tot += v[r];
+            }
+            int incl = tot;
+#pragma unroll
+            for (int mm = 1; mm < kWave; mm <<= 1) {
+                const int up = __shfl_up(incl, mm, kWave);
+                if (tid >= mm) incl += up;
+            }
+            int run = incl - tot;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                start[tid * R + r] = run;
+                run += v[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if (cell[j] >= 0) sorted[start[cell[j]] + slot[j]] = rec[j];
+        __syncthreads();
+
+        // ---- walk: LDS only ------------------------------------------------------------------------------------------------
+        const int mine = owner ? cnt[tid] : 0, first = owner ? start[tid] : 0;
+        for (int k = 0; k < mine; ++k) {
+            const StagedRec r = sorted[first + k];
+            float w[4];
+            weights_from_fraction(r.fx, r.fy, r.mask, w);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc[kk][c] = fmaf(r.dw[c], w[kk], acc[kk][c]);
+        }
+        __syncthreads();                                           // `sorted`, `cnt`, `start` are rewritten by the next chunk
+    }
+
+    // ---- fold the four tap images into the tile: within a pass every lane targets its own pixel ----------------------------
+    __syncthreads();                                               // an empty tile gets here without any barrier since `out` was zeroed
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int lx = cbx - 1 + (kk & 1), ly = cby - 1 + (kk >> 1);
+        if (owner && (unsigned)lx < (unsigned)TW && (unsigned)ly < (unsigned)TH) {
+            float4* __restrict__ o = reinterpret_cast<float4*>(&out[(ly * TW + lx) * C]);
+            float4 u = o[0], v = o[1];
+            u.x += acc[kk][0]; u.y += acc[kk][1]; u.z += acc[kk][2]; u.w += acc[kk][3];
+            v.x += acc[kk][4]; v.y += acc[kk][5]; v.z += acc[kk][6]; v.w += acc[kk][7];
+            o[0] = u;
+            o[1] = v;
+        }
+        __syncthreads();
+    }
+    float* __restrict__ gsrc = a.gsrcs.p[s] + (size_t)b * HWs * C;
+    for (int e = tid; e < TH * TW * C / 4; e += NT) {
+        const int cellp = (4 * e) / C, chn = (4 * e) % C;
+        const int lx = cellp & (TW - 1), ly = cellp >> LW;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < dm.Ws && gy < dm.Hs)
+            *reinterpret_cast<float4*>(gsrc + ((size_t)gy * dm.Ws + gx) * C + chn) = *reinterpret_cast<const float4*>(&out[cellp * C + chn]);
+    }
+}
+
+template <int C, int G>
+static int launch_owner(const OwnerArgs& a, int D, hipStream_t st) {
+    const dim3 grid((unsigned)(((a.nbins + 7) / 8) * 8)), block(OwnerTile<C>::NT);
+    if constexpr (C == 8) {
+        if (D == 4) hipLaunchKernelGGL((tile_owner_c8_kernel<G, 4>), grid, block, 0, st, a);
+        else if (D == 8) hipLaunchKernelGGL((tile_owner_c8_kernel<G, 8>), grid, block, 0, st, a);
+        else if (D == 16) hipLaunchKernelGGL((tile_owner_c8_kernel<G, 16>), grid, block, 0, st, a);
+        else return MVSTER_ERR_UNSUPPORTED;
+        return launch_status();
+    }
+    if (D == 4) hipLaunchKernelGGL((tile_owner_kernel<C, G, 4>), grid, block, 0, st, a);
+    else if (D == 8) hipLaunchKernelGGL((tile_owner_kernel<C, G, 8>), grid, block, 0, st, a);
+    else if (D == 16) hipLaunchKernelGGL((tile_owner_kernel<C, G, 16>), grid, block, 0, st, a);
+    else return MVSTER_ERR_UNSUPPORTED;
+    return launch_status();
+}
+
+template <bool FILL>
+static int launch_bin_items(const BinArgs& ba, int B, int D, int* counters, int* items, hipStream_t st) {
+    const VolumeDims& dm = ba.dm;
+    BinArgs a = ba;
+    const int bhp = kBlock / D / 8;
+    a.blocks_x = (dm.W + 7) / 8;
+    const dim3 grid((unsigned)(a.blocks_x * ((dm.H + bhp - 1) / bhp)), (unsigned)B);
+    if (D == 4) hipLaunchKernelGGL((bin_items_kernel<FILL, 4>), grid, dim3(kBlock), 0, st, a, counters, items);
+    else if (D == 8) hipLaunchKernelGGL((bin_items_kernel<FILL, 8>), grid, dim3(kBlock), 0, st, a, counters, items);
+    else if (D == 16) hipLaunchKernelGGL((bin_items_kernel<FILL, 16>), grid, dim3(kBlock), 0, st, a, counters, items);
+    else return MVSTER_ERR_UNSUPPORTED;
+    return launch_status();
+}
+
+int launch_binned_scatter(const float* ref, const float* pose, const float* hypo, const GradPtrs& gsrcs, int B, int C, int G,
+                          int D, const VolumeDims& dm, float* workspace, const BinnedLayout& lay, hipStream_t st) {
+    const BinGrid bg = bin_grid_for(C, dm.Hs, dm.Ws);
+    int* const words = reinterpret_cast<int*>(workspace);
+    int* const counts = words + lay.counts;
+    int* const partials = words + lay.partials;
+    int* const offsets = words + lay.offsets;
+    int* const cursor = words + lay.cursor;
+    int* const items = words + lay.items;
+    const int nbins = (int)lay.nbins;
+    if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)nbins, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return MVSTER_ERR_LAUNCH;
+    }
+    BinArgs ba{pose, hypo, dm, bg, bg.tiles_x * bg.tiles_y, 0};
+    if (int rc = launch_bin_items<false>(ba, B, D, counts, nullptr, st)) return rc;
+    const int nblocks = grid_for(nbins, kScanBlock);
+    hipLaunchKernelGGL(bin_scan_partials_kernel, dim3(nblocks), dim3(kScanBlock), 0, st, counts, partials, nbins);
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL(bin_scan_apply_kernel, dim3(nblocks), dim3(kScanBlock), 0, st, counts, partials, offsets, cursor, nbins);
+    if (int rc = launch_status()) return rc;
+    if (int rc = launch_bin_items<true>(ba, B, D, cursor, items, st)) return rc;
+    OwnerArgs oa{workspace + lay.coef, ref, pose, hypo, offsets, items, gsrcs, dm, bg, bg.tiles_x * bg.tiles_y, nbins};
+#define X(C_, G_) \
+    if (C == C_ && G == G_) return launch_owner<C_, G_>(oa, D, st);
+    X(8, 4) X(16, 4) X(32, 4) X(64, 4) X(8, 8) X(16, 8) X(32, 8) X(64, 8)
+#undef X
+    return MVSTER_ERR_UNSUPPORTED;
+}
+
+}  // namespace mvster

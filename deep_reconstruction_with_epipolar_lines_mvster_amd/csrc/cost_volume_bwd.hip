@@ -621,17 +621,21 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
     }
 }
 
-// deferred route (see DEFER above): coefficients first, then the tiled scatter of cost_volume_scatter.hip
+// deferred routes (see DEFER above): coefficients first, then either the tiled LDS-merged atomic scatter of
+// cost_volume_scatter.hip or the binned, atomics-free scatter of cost_volume_binned.hip
 template <int CPG, int G, int D>
 static int launch_bwd_deferred(const float* gvol, const float* vol, const float* wsum, const float* ref, const SrcPtrs& srcs,
                                const float* pose, const float* hypo, float* gref, const GradPtrs& gsrcs, int B,
-                               VolumeDims dm, float* dcor, hipStream_t st) {
+                               VolumeDims dm, int route, float* workspace, const BinnedLayout& lay, hipStream_t st) {
     constexpr int PXB = kBlock / D;
     dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
+    float* const dcor = workspace + (route == MVSTER_BWD_ROUTE_BINNED ? lay.coef : 0);
     hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, 1, true>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
                        ref, srcs, pose, hypo, gref, gsrcs, dm, dcor);
     if (int rc = launch_status()) return rc;
+    if (route == MVSTER_BWD_ROUTE_BINNED)
+        return launch_binned_scatter(ref, pose, hypo, gsrcs, B, CPG * G, G, D, dm, workspace, lay, st);
     return launch_tile_scatter(dcor, ref, pose, hypo, gsrcs, B, CPG * G, G, D, dm, st);
 }
 
@@ -667,16 +671,40 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
 
 }  // namespace mvster
 
-extern "C" long long mvster_cost_volume_bwd_workspace(int S, int B, int C, int G, int D, int H, int W, int layout) {
+extern "C" long long mvster_cost_volume_bwd_route_workspace(int route, int S, int B, int C, int G, int D, int H, int W,
+                                                            int Hs, int Ws, int layout) {
     using namespace mvster;
-    if (S <= 0 || B <= 0 || G <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    if (!tile_scatter_applies(C, G, D, layout)) return 0;
-    return (long long)B * S * H * W * D * G;
+    if (S <= 0 || B <= 0 || G <= 0 || D <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0) return -1;
+    if (!shape_instantiated(C, G, D)) return -1;
+    BinnedLayout lay;
+    switch (route) {
+        case MVSTER_BWD_ROUTE_PLANAR: return layout == MVSTER_LAYOUT_NCHW ? 0 : -1;
+        case MVSTER_BWD_ROUTE_DENSE:
+            return layout == MVSTER_LAYOUT_NHWC && !pick_pixel_per_lane(B, H * W, C, D) ? 0 : -1;
+        case MVSTER_BWD_ROUTE_SPLIT_WINDOW:
+            return layout == MVSTER_LAYOUT_NHWC && pick_pixel_per_lane(B, H * W, C, D) ? 0 : -1;
+        case MVSTER_BWD_ROUTE_TILE_SCATTER:
+            return tile_scatter_applies(C, G, D, layout) ? (long long)B * S * H * W * D * G : -1;
+        case MVSTER_BWD_ROUTE_BINNED:
+            return layout == MVSTER_LAYOUT_NHWC && binned_layout(S, B, C, G, D, H, W, Hs, Ws, &lay) ? lay.total : -1;
+        default: return -1;
+    }
 }
 
-extern "C" int mvster_cost_volume_bwd_route(int S, int B, int C, int G, int D, int H, int W, int layout,
+extern "C" long long mvster_cost_volume_bwd_workspace(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws,
+                                                      int layout) {
+    using namespace mvster;
+    if (layout != MVSTER_LAYOUT_NHWC) return 0;
+    long long need = -1;
+    if (C >= kMinBinnedChannels) need = mvster_cost_volume_bwd_route_workspace(MVSTER_BWD_ROUTE_BINNED, S, B, C, G, D, H, W, Hs, Ws, layout);
+    if (need < 0 && pick_pixel_per_lane(B, H * W, C, D)) return 0;         // the lane-split window kernel needs none
+    if (need < 0) need = mvster_cost_volume_bwd_route_workspace(MVSTER_BWD_ROUTE_TILE_SCATTER, S, B, C, G, D, H, W, Hs, Ws, layout);
+    return need < 0 ? 0 : need;
+}
+
+extern "C" int mvster_cost_volume_bwd_route(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, int layout,
                                             long long workspace_floats) {
-    return mvster::pick_bwd_route(S, B, C, G, D, H, W, layout, workspace_floats);
+    return mvster::pick_bwd_route(S, B, C, G, D, H, W, Hs, Ws, layout, workspace_floats);
 }
 
 extern "C" int mvster_cost_volume_bwd_route_name(int route, int C, int G, int D, char* buf, int cap) {
@@ -696,6 +724,10 @@ extern "C" int mvster_cost_volume_bwd_route_name(int route, int C, int G, int D,
             break;
         case MVSTER_BWD_ROUTE_TILE_SCATTER:
             n = snprintf(tmp, sizeof tmp, "tile_scatter_kernel<128, 8>");
+            break;
+        case MVSTER_BWD_ROUTE_BINNED:
+            if (C == 8) n = snprintf(tmp, sizeof tmp, "tile_owner_c8_kernel<%d, %d>", G, D);
+            else n = snprintf(tmp, sizeof tmp, "tile_owner_kernel<%d, %d, %d>", C, G, D);
             break;
         default:
             tmp[0] = 0;
@@ -730,22 +762,29 @@ extern "C" int mvster_cost_volume_bwd_ws(const float* gvol, const float* vol, co
         gp.p[s] = gsrcs[s];
     }
     const hipStream_t st = as_stream(stream);
-    for (int s = 0; s < S; ++s) {
-        if (hipMemsetAsync(gp.p[s], 0, sizeof(float) * (size_t)B * C * Hs * Ws, st) != hipSuccess) {
-            (void)hipGetLastError();
-            return MVSTER_ERR_LAUNCH;
+    const int route = pick_bwd_route(S, B, C, G, D, H, W, Hs, Ws, layout, workspace != nullptr ? workspace_floats : 0);
+    BinnedLayout lay{};
+    if (route == MVSTER_BWD_ROUTE_BINNED) binned_layout(S, B, C, G, D, H, W, Hs, Ws, &lay);
+    if (route != MVSTER_BWD_ROUTE_BINNED) {          // the binned route writes every gradient element itself
+        for (int s = 0; s < S; ++s) {
+            if (hipMemsetAsync(gp.p[s], 0, sizeof(float) * (size_t)B * C * Hs * Ws, st) != hipSuccess) {
+                (void)hipGetLastError();
+                return MVSTER_ERR_LAUNCH;
+            }
         }
     }
     VolumeDims dm{H, W, Hs, Ws, S, 0, attn_temp, (float)sqrt((double)C)};
     const int cpg = C / G;
-    const bool wide = pick_pixel_per_lane(B, H * W, C, D);
-    const long long need = mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, layout);
-    const bool deferred = need > 0 && workspace != nullptr && workspace_floats >= need;
+    const bool deferred = route == MVSTER_BWD_ROUTE_BINNED || route == MVSTER_BWD_ROUTE_TILE_SCATTER;
+    const bool wide = route == MVSTER_BWD_ROUTE_SPLIT_WINDOW || (route == MVSTER_BWD_ROUTE_PLANAR && pick_pixel_per_lane(B, H * W, C, D));
+#define DEFERRED(CPG_, G_, D_) \
+    return launch_bwd_deferred<CPG_, G_, D_>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, route, workspace, lay, st)
 #define X(CPG_, G_)                                                                                                   \
     if (cpg == CPG_ && G == G_) {                                                                                     \
-        if constexpr (CPG_ * G_ >= 16) {                                                                              \
-            if (deferred && D == 8)                                                                                   \
-                return launch_bwd_deferred<CPG_, G_, 8>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, workspace, st); \
+        if (deferred) {                                                                                               \
+            if (D == 4) DEFERRED(CPG_, G_, 4);                                                                        \
+            if (D == 8) DEFERRED(CPG_, G_, 8);                                                                        \
+            if (D == 16) DEFERRED(CPG_, G_, 16);                                                                      \
         }                                                                                                             \
         if constexpr (CPG_ * G_ <= kMaxWideChannels) {                                                                \
             if (D == 4 && wide)                                                                                       \
@@ -757,5 +796,6 @@ extern "C" int mvster_cost_volume_bwd_ws(const float* gvol, const float* vol, co
     }
     MVSTER_FOR_SHAPES(X)
 #undef X
+#undef DEFERRED
     return MVSTER_ERR_UNSUPPORTED;
 }

@@ -53,12 +53,80 @@ inline bool tile_scatter_applies(int C, int G, int D, int layout) {
     return layout == MVSTER_LAYOUT_NHWC && D == 8 && (C == 16 || C == 32 || C == 64) && shape_instantiated(C, G, D);
 }
 
+// ---- binned (atomics-free) backward, cost_volume_binned.hip ---------------------------------------------------------
+// The source map of every (batch, view) is cut into tiles of 2^lw x 2^lh pixels; a tile is one bin of the counting sort
+// and one workgroup of the accumulate kernel, whose LDS holds the tile as C doubles per pixel.
+struct BinGrid {
+    int lw, lh;               // log2 of the tile width / height in source pixels
+    int tiles_x, tiles_y;     // tiles per source map
+};
+
+// tile area x C x 4 B of LDS for the tile image: 4 / 8 / 16 / 16 KB per workgroup
+template <int C> struct BinTile;
+template <> struct BinTile<8> { static constexpr int kLw = 4, kLh = 3; };     // 16 x 8
+template <> struct BinTile<16> { static constexpr int kLw = 4, kLh = 3; };    // 16 x 8
+template <> struct BinTile<32> { static constexpr int kLw = 4, kLh = 3; };    // 16 x 8
+template <> struct BinTile<64> { static constexpr int kLw = 3, kLh = 3; };    //  8 x 8
+
+inline BinGrid bin_grid_for(int C, int Hs, int Ws) {
+    BinGrid g{};
+    g.lw = C == 8 ? BinTile<8>::kLw : C == 16 ? BinTile<16>::kLw : C == 32 ? BinTile<32>::kLw : BinTile<64>::kLw;
+    g.lh = C == 8 ? BinTile<8>::kLh : C == 16 ? BinTile<16>::kLh : C == 32 ? BinTile<32>::kLh : BinTile<64>::kLh;
+    g.tiles_x = (Ws + (1 << g.lw) - 1) >> g.lw;
+    g.tiles_y = (Hs + (1 << g.lh) - 1) >> g.lh;
+    return g;
+}
+
+// Workspace of the binned route, in 4-byte words: per-hypothesis group coefficients [B,S,HW,D,G] (float), then the
+// counting sort's arrays (int): counts[nbins], partials[nbins / 1024 rounded up] (scan), offsets[nbins + 1], cursor[nbins],
+// items[4 * B*S*HW*D] -- an item (pixel, hypothesis) of one view is listed in every tile its 2x2 footprint touches, at
+// most four.
+struct BinnedLayout {
+    long long coef, counts, partials, offsets, cursor, items, total;     // word offsets; total = words needed
+    long long nbins, max_items;
+};
+
+constexpr long long kMaxBinnedItems = (1LL << 31) - 1;           // 32-bit item positions
+constexpr long long kMaxBins = 1LL << 22;                        // single-workgroup scan
+
+// Measured on MI355X against the atomic routes (B = 4, S = 4, noise / smooth-scene hypotheses, ms per backward):
+//   DTU stage 1 (C 64, D 8) 0.96 / 0.96 vs 1.50 / 1.50      stage 2 (C 32, D 8) 2.13 / 1.84 vs 3.35 / 2.47
+//   stage 3 (C 16, D 4) 2.47 / 1.98 vs 3.02 / 3.43          stage 4 (C 8, D 4)  6.31 / 5.15 vs 7.07 / 7.62
+// so the binned route is the recommendation wherever it exists: mvster_cost_volume_bwd_workspace() asks for its scratch.
+constexpr int kMinBinnedChannels = 8;
+
+inline bool binned_layout(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, BinnedLayout* out) {
+    if (!(C == 8 || C == 16 || C == 32 || C == 64) || !shape_instantiated(C, G, D)) return false;
+    if (S <= 0 || B <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0) return false;
+    const BinGrid g = bin_grid_for(C, Hs, Ws);
+    BinnedLayout l{};
+    l.nbins = (long long)B * S * g.tiles_x * g.tiles_y;
+    l.max_items = 4LL * B * S * H * W * D;
+    if (l.max_items > kMaxBinnedItems || l.nbins > kMaxBins || (long long)H * W * D > kMaxBinnedItems) return false;
+    auto align4 = [](long long v) { return (v + 3) & ~3LL; };
+    l.coef = 0;
+    l.counts = align4((long long)B * S * H * W * D * G);
+    l.partials = align4(l.counts + l.nbins);
+    l.offsets = align4(l.partials + (l.nbins + 1023) / 1024);
+    l.cursor = align4(l.offsets + l.nbins + 1);
+    l.items = align4(l.cursor + l.nbins);
+    l.total = align4(l.items + l.max_items);
+    if (out != nullptr) *out = l;
+    return true;
+}
+
+int launch_binned_scatter(const float* ref, const float* pose, const float* hypo, const GradPtrs& gsrcs, int B, int C, int G,
+                          int D, const VolumeDims& dm, float* workspace, const BinnedLayout& lay, hipStream_t st);
+
 // Which kernel family the backward entry point runs for a shape (mvster_cost_volume_bwd_route in mvster_hip.h).
-inline int pick_bwd_route(int S, int B, int C, int G, int D, int H, int W, int layout, long long workspace_floats) {
+inline int pick_bwd_route(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, int layout,
+                          long long workspace_floats) {
     if (S <= 0 || B <= 0 || H <= 0 || W <= 0 || !shape_instantiated(C, G, D)) return MVSTER_BWD_ROUTE_NONE;
     if (layout != MVSTER_LAYOUT_NHWC) return MVSTER_BWD_ROUTE_PLANAR;
+    BinnedLayout lay;
+    if (binned_layout(S, B, C, G, D, H, W, Hs, Ws, &lay) && workspace_floats >= lay.total) return MVSTER_BWD_ROUTE_BINNED;
     if (tile_scatter_applies(C, G, D, layout) && workspace_floats >= (long long)B * S * H * W * D * G)
-        return MVSTER_BWD_ROUTE_TILE_SCATTER;
+        return MVSTER_BWD_ROUTE_TILE_SCATTER;        // a caller that only offers the round-1 workspace size
     if (pick_pixel_per_lane(B, H * W, C, D)) return MVSTER_BWD_ROUTE_SPLIT_WINDOW;
     return MVSTER_BWD_ROUTE_DENSE;
 }

@@ -56,7 +56,18 @@ struct Taps {
     float w00, w01, w10, w11;
     int ix, iy;                  // floor of the sample position (limited to [-2, size+1]); tap (dy,dx) = (iy+dy, ix+dx)
     int mask;                    // bit (2*dy+dx) set when that tap lies inside the source map
+    float fx, fy;                // fractional sample position: w00 = (1-fy)(1-fx), w01 = (1-fy) fx, w10 = fy (1-fx), w11 = fy fx
 };
+
+// The four bilinear weights from the fractional position, with the products formed exactly as project_taps() forms them;
+// taps outside the source map (mask bit clear) get weight 0 -- the backward weights, see masked_weight().
+__device__ __forceinline__ void weights_from_fraction(float fx, float fy, int mask, float (&w)[4]) {
+    const float fe = 1.0f - fx, fs = 1.0f - fy;
+    w[0] = (mask & 1) ? fs * fe : 0.0f;
+    w[1] = (mask & 2) ? fs * fx : 0.0f;
+    w[2] = (mask & 4) ? fy * fe : 0.0f;
+    w[3] = (mask & 8) ? fy * fx : 0.0f;
+}
 
 // Backward weight of tap k: zero unless the tap is inside the map.  (A NaN sample position keeps NaN weights in
 // the forward pass so that NaN propagates like in the reference; its backward scatters nothing, as grid_sample's.)
@@ -110,6 +121,8 @@ __device__ __forceinline__ Taps project_taps(const Pose& q, const Ray& r, float 
     t.ix = (int)fminf(fmaxf(xw, -2.0f), wmax + 1.0f);
     t.iy = (int)fminf(fmaxf(yn, -2.0f), hmax + 1.0f);
     t.mask = (int)(x0in & y0in) | ((int)(x1in & y0in) << 1) | ((int)(x0in & y1in) << 2) | ((int)(x1in & y1in) << 3);
+    t.fx = fw;
+    t.fy = fn;
     return t;
 }
 

@@ -167,7 +167,11 @@ def to_planar(t):
     return out
 
 
-TILE_SCATTER = True      # backward of the coarse stages: coefficients + tiled LDS-merged scatter (see mvster_hip.h, A3)
+# Scratch the backward may use (see mvster_hip.h, A3): "full" = what the library recommends for the shape (the binned,
+# atomics-free scatter for C >= 16), "binned" = the binned route's scratch even where it is not the recommendation,
+# "coefficients" = only the per-hypothesis coefficients (round-1 tiled scatter where it applies), "none" = the plain
+# atomic routes.  Tests and tools switch it to compare the routes; product code leaves it alone.
+BWD_WORKSPACE = "full"
 
 
 class _FusedCostVolume(torch.autograd.Function):
@@ -215,9 +219,15 @@ class _FusedCostVolume(torch.autograd.Function):
         grads = [torch.empty_like(f) for f in feats]        # same storage layout as the kernel-side features
         pp, keep = _lib.ptr_array(srcs)
         gp, gkeep = _lib.ptr_array(grads[1:])
-        # scratch for the two-kernel route of the coarse stages (0 floats when it does not apply); torch's caching
-        # allocator owns it, the library never allocates
-        need = _lib.load().mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, layout) if TILE_SCATTER else 0
+        # scratch for the multi-kernel routes (0 words when none applies); torch's caching allocator owns it, the library
+        # never allocates
+        need = 0
+        if BWD_WORKSPACE == "full":
+            need = _lib.bwd_workspace(S, B, C, G, D, H, W, Hs, Ws, layout)
+        elif BWD_WORKSPACE == "binned":
+            need = max(0, _lib.bwd_workspace(S, B, C, G, D, H, W, Hs, Ws, layout, route="binned"))
+        elif BWD_WORKSPACE == "coefficients" and layout == _lib.LAYOUT_NHWC:
+            need = B * S * H * W * D * G
         ws = torch.empty(need, dtype=torch.float32, device=ref.device) if need > 0 else None
         with _on(ref.device):
             _lib.call("mvster_cost_volume_bwd_ws", gvol.data_ptr(), vol.data_ptr(), wsum.data_ptr(), ref.data_ptr(), pp, S,

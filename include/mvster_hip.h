@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MVSTER_ABI_VERSION 1
+#define MVSTER_ABI_VERSION 2
 
 #define MVSTER_OK 0
 #define MVSTER_ERR_NULL_POINTER 1   /* a required pointer argument is NULL                     */
@@ -115,14 +115,26 @@ int mvster_cost_volume_bwd(const float *gvol, const float *vol, const float *wsu
                            float *gref, float *const *gsrcs, int B, int C, int G, int D, int H, int W,
                            int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream);
 
-/* A3 with caller-provided scratch memory.  Same operation and results (to fp32 summation order); with a workspace
- * of at least mvster_cost_volume_bwd_workspace(...) floats the stages with D = 8 hypotheses (channels-last, C in {16,32,64})
- * take the two-kernel route: per-hypothesis coefficients first, then a tiled scatter that merges the taps of an 8x8
- * pixel block in LDS before they reach memory (4-9x fewer atomic requests).  workspace == NULL, a short workspace or
- * any other shape: identical to mvster_cost_volume_bwd.  The library never allocates.
- *   mvster_cost_volume_bwd_workspace : floats needed for this shape, 0 when the route does not apply.
+/* A3 with caller-provided scratch memory.  Same operation and results (to summation order).  With a workspace of at
+ * least mvster_cost_volume_bwd_workspace(...) 4-byte words the channels-last backward takes the BINNED route, which
+ * issues no global float atomic: a coefficient kernel (everything that needs the feature gathers: correlations,
+ * softmax, reference gradient, and G coefficients per (view, pixel, hypothesis)), a counting sort of the
+ * (pixel, hypothesis) samples by destination tile of the source map, and one workgroup per tile that sorts its samples
+ * by source pixel in LDS, sums them in registers (one owner lane per pixel) and writes the tile once with plain stores.
+ * The workspace holds the
+ * coefficients [B,S,H*W,D,G] and the sort's arrays (worst case 4 tile entries per sample): see DESIGN.md section 3.
+ * A workspace of only B*S*H*W*D*G words selects the round-1 TILE_SCATTER route for D = 8, C >= 16;
+ * workspace == NULL or anything shorter: identical to mvster_cost_volume_bwd.  The library never allocates.
+ *   mvster_cost_volume_bwd_workspace : words the RECOMMENDED (fastest measured) route of this shape wants, 0 when it
+ *       wants none.  The entry point takes the binned route whenever the workspace is large enough for it, the
+ *       recommendation only decides what the query asks for (C = 8: nothing, the lane-split window kernel is faster).
+ *   mvster_cost_volume_bwd_route_workspace : words a given MVSTER_BWD_ROUTE_* needs for this shape (0: none),
+ *       -1 when that route does not exist for the shape / layout.
  */
-long long mvster_cost_volume_bwd_workspace(int S, int B, int C, int G, int D, int H, int W, int layout);
+long long mvster_cost_volume_bwd_workspace(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws,
+                                           int layout);
+long long mvster_cost_volume_bwd_route_workspace(int route, int S, int B, int C, int G, int D, int H, int W, int Hs,
+                                                 int Ws, int layout);
 int mvster_cost_volume_bwd_ws(const float *gvol, const float *vol, const float *wsum, const float *ref,
                               const float *const *srcs, int S, const float *pose, const float *hypo,
                               float *gref, float *const *gsrcs, int B, int C, int G, int D, int H, int W,
@@ -132,14 +144,15 @@ int mvster_cost_volume_bwd_ws(const float *gvol, const float *vol, const float *
 /* Which kernel family mvster_cost_volume_bwd_ws runs for a shape and workspace size (so that tests and the
  * benchmark can state -- and assert -- the route instead of mirroring the dispatch rules).
  * mvster_cost_volume_bwd_route_name: the route's dominant kernel as rocprofv3 prints it, e.g.
- * "cost_volume_bwd_nhwc_split_kernel<8, 4, 4, 2>"; writes at most `cap` bytes including the terminator and returns
+ * "tile_owner_kernel<8, 4, 4>"; writes at most `cap` bytes including the terminator and returns
  * the length it wanted to write (0 for MVSTER_BWD_ROUTE_NONE). */
 #define MVSTER_BWD_ROUTE_NONE 0          /* shape not instantiated: the entry point returns MVSTER_ERR_UNSUPPORTED   */
 #define MVSTER_BWD_ROUTE_PLANAR 1        /* NCHW planes, tap-by-tap atomics                                           */
 #define MVSTER_BWD_ROUTE_DENSE 2         /* channels-last, one LDS-transposed dense atomic strip per hypothesis       */
 #define MVSTER_BWD_ROUTE_SPLIT_WINDOW 3  /* channels-last, D = 4, C <= 16: per-pixel hypothesis window, 2/4 lanes per pixel */
 #define MVSTER_BWD_ROUTE_TILE_SCATTER 4  /* channels-last, D = 8: coefficient kernel + tiled LDS write-combining scatter  */
-int mvster_cost_volume_bwd_route(int S, int B, int C, int G, int D, int H, int W, int layout,
+#define MVSTER_BWD_ROUTE_BINNED 5        /* channels-last: coefficient kernel + counting sort by tile + owner lanes, no float atomics */
+int mvster_cost_volume_bwd_route(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, int layout,
                                  long long workspace_floats);
 int mvster_cost_volume_bwd_route_name(int route, int C, int G, int D, char *buf, int cap);
 

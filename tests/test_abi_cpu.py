@@ -92,18 +92,46 @@ def test_fused_support_table_matches_library(lib):
                 assert (rc == 1) == rc_expected_supported, (C, G, D, rc)
 
 
-def test_backward_workspace_query(lib):
-    """mvster_cost_volume_bwd_workspace is pure host arithmetic: B*S*H*W*D*G floats (the per-hypothesis group
-    coefficients) exactly for the shapes that take the two-kernel backward, 0 for every other shape or layout."""
-    q = lib.mvster_cost_volume_bwd_workspace          # (S, B, C, G, D, H, W, layout)
-    assert q(4, 4, 32, 8, 8, 296, 400, _lib.LAYOUT_NHWC) == 4 * 4 * 296 * 400 * 8 * 8
-    assert q(4, 1, 64, 8, 8, 148, 200, _lib.LAYOUT_NHWC) == 4 * 148 * 200 * 8 * 8
-    assert q(9, 1, 16, 4, 8, 768, 1024, _lib.LAYOUT_NHWC) == 9 * 768 * 1024 * 8 * 4          # hi-res config, stage 3
-    assert q(16, 65535, 64, 4, 8, 1184, 1600, _lib.LAYOUT_NHWC) == 16 * 65535 * 1184 * 1600 * 8 * 4     # > 2^32 floats
-    for args in ((4, 4, 32, 8, 8, 296, 400, _lib.LAYOUT_NCHW), (4, 4, 16, 4, 4, 592, 800, _lib.LAYOUT_NHWC),
-                 (4, 4, 8, 4, 4, 1184, 1600, _lib.LAYOUT_NHWC), (4, 4, 32, 8, 4, 296, 400, _lib.LAYOUT_NHWC),
-                 (4, 4, 48, 8, 8, 296, 400, _lib.LAYOUT_NHWC), (0, 4, 32, 8, 8, 296, 400, _lib.LAYOUT_NHWC),
-                 (4, 4, 32, 8, 8, 0, 400, _lib.LAYOUT_NHWC)):
+def test_backward_workspace_and_route_queries(lib):
+    """mvster_cost_volume_bwd_workspace / _route are pure host arithmetic.  The binned route wants the coefficients
+    [B,S,HW,D,G] plus the counting sort's arrays (counts, offsets, cursor per tile; 4 tile entries per (view, pixel,
+    hypothesis) sample at worst); offering only the coefficients selects the round-1 tiled scatter where it exists;
+    planar layout or unsupported shapes want nothing."""
+    q, route = _lib.bwd_workspace, _lib.bwd_route
+    NH = _lib.LAYOUT_NHWC
+
+    def expected(S, B, C, G, D, H, W, Hs, Ws):
+        tw, th = {8: (16, 8), 16: (16, 8), 32: (16, 8), 64: (8, 8)}[C]
+        nb = B * S * (-(-Ws // tw)) * (-(-Hs // th))
+        al = lambda v: (v + 3) & ~3
+        counts = al(B * S * H * W * D * G)
+        partials = al(counts + nb)
+        offsets = al(partials + -(-nb // 1024))
+        cursor = al(offsets + nb + 1)
+        items = al(cursor + nb)
+        return al(items + 4 * B * S * H * W * D)
+
+    for args in ((4, 4, 32, 8, 8, 296, 400, 296, 400), (4, 1, 64, 8, 8, 148, 200, 148, 200), (9, 1, 16, 4, 8, 768, 1024, 768, 1024),
+                 (4, 4, 8, 4, 4, 1184, 1600, 1184, 1600), (2, 3, 16, 8, 16, 33, 47, 30, 50)):
+        need = q(*args, NH, route="binned")
+        assert need == expected(*args)
+        assert q(*args, NH) == need                 # the recommendation is the binned route wherever it exists
+        assert route(*args, NH, need)[1] == "binned"
+        assert route(*args, NH, need - 1)[1] != "binned"
+    S, B, C, G, D, H, W = 4, 4, 32, 8, 8, 296, 400
+    assert route(S, B, C, G, D, H, W, H, W, NH, B * S * H * W * D * G)[1] == "tile_scatter"
+    assert route(S, B, C, G, D, H, W, H, W, NH, B * S * H * W * D * G - 1)[1] == "dense"
+    assert route(4, 4, 8, 4, 4, 1184, 1600, 1184, 1600, NH, 0)[:2] == (3, "split_window")
+    assert route(4, 4, 8, 4, 4, 1184, 1600, 1184, 1600, NH, 0)[2] == "cost_volume_bwd_nhwc_split_kernel<8, 4, 4, 2>"
+    assert route(4, 1, 16, 4, 4, 592, 800, 592, 800, NH, 0)[1] == "dense"              # too few pixels for the lane split
+    assert route(4, 4, 32, 8, 8, 296, 400, 296, 400, _lib.LAYOUT_NCHW, 10 ** 12)[1] == "planar"
+    assert route(4, 4, 48, 8, 8, 296, 400, 296, 400, NH, 10 ** 12)[1] == "none"
+    # more than 2^31 item slots: the binned route does not apply, the coefficient-only routes still do
+    assert q(16, 64, 64, 4, 8, 1184, 1600, 1184, 1600, NH) == 16 * 64 * 1184 * 1600 * 8 * 4
+    assert q(16, 64, 64, 4, 8, 1184, 1600, 1184, 1600, NH, route="binned") == -1
+    assert q(4, 1, 8, 4, 4, 64, 80, 64, 80, NH, route="split_window") == -1 and q(4, 4, 8, 4, 4, 1184, 1600, 1184, 1600, NH, route="split_window") == 0
+    for args in ((4, 4, 32, 8, 8, 296, 400, 296, 400, _lib.LAYOUT_NCHW), (4, 4, 48, 8, 8, 296, 400, 296, 400, NH),
+                 (0, 4, 32, 8, 8, 296, 400, 296, 400, NH), (4, 4, 32, 8, 8, 0, 400, 296, 400, NH)):
         assert q(*args) == 0
     # the _ws entry point validates like the plain one before touching the device
     rc = lib.mvster_cost_volume_bwd_ws(None, None, None, None, None, 1, None, None, None, None, 1, 32, 8, 8, 4, 4, 4, 4,

@@ -53,6 +53,30 @@ def close(actual, expected, rel, abs_=1e-6, what="", exact=None):
     return err
 
 
+class backward_workspace:
+    """Select the scratch the backward may use (hotpath.BWD_WORKSPACE) -- and with it the scatter route -- for a block."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from deep_reconstruction_with_epipolar_lines_mvster_amd import hotpath
+        self.prev, hotpath.BWD_WORKSPACE = hotpath.BWD_WORKSPACE, self.mode
+
+    def __exit__(self, *exc):
+        from deep_reconstruction_with_epipolar_lines_mvster_amd import hotpath
+        hotpath.BWD_WORKSPACE = self.prev
+
+
+def route_for(mode, S, B, C, G, D, H, W, Hs=None, Ws=None):
+    """Label of the backward route hotpath takes under a workspace mode (asked from the library itself)."""
+    Hs, Ws = Hs or H, Ws or W
+    need = {"full": _lib.bwd_workspace(S, B, C, G, D, H, W, Hs, Ws, _lib.LAYOUT_NHWC),
+            "binned": max(0, _lib.bwd_workspace(S, B, C, G, D, H, W, Hs, Ws, _lib.LAYOUT_NHWC, route="binned")),
+            "coefficients": B * S * H * W * D * G, "none": 0}[mode]
+    return _lib.bwd_route(S, B, C, G, D, H, W, Hs, Ws, _lib.LAYOUT_NHWC, need)[1]
+
+
 # ------------------------------------------------------------------------------------------ poses
 def test_stage_poses_match_fp32_reference_algebra(dev):
     g = torch.Generator().manual_seed(5)
@@ -324,11 +348,12 @@ def test_layout_routes_agree(dev, C, G, D, H, W):
 @pytest.mark.parametrize("stage,coherent", [(3, False), (3, True), (2, False), (2, True), (1, False), (1, True),
                                             (0, False), (0, True)])
 def test_backward_scatter_paths_agree_full_size(dev, stage, coherent):
-    """The channels-last backward has several scatter paths: the per-lane hypothesis window (C <= 16, one or two lanes
-    per pixel), dense per-hypothesis strips, and - for the coarse stages (D = 8, C >= 32) when a workspace is passed -
-    the two-kernel route whose tiled scatter merges taps in a wave-private LDS cache (evictions on spatially random
-    hypotheses, mostly hits on smooth ones).  At full DTU stage shapes all of them must give the gradients of the
-    planar (NCHW) kernel family, which scatters tap by tap."""
+    """The channels-last backward has several scatter routes: the binned one (counting sort by destination tile + LDS
+    double-precision tiles, no atomics to memory; needs the full workspace), and the atomic ones it falls back to with
+    less scratch -- the coefficient kernel + tiled LDS write-combining scatter (D = 8, C >= 16), the per-pixel hypothesis
+    window with 2/4 lanes per pixel (D = 4, C <= 16, enough pixels) and dense per-hypothesis strips.  At full DTU stage
+    shapes, on smooth and on spatially random hypotheses, all of them must give the gradients of the planar (NCHW) kernel
+    family, which scatters tap by tap."""
     H, W, C, G, D, scale = DTU_STAGES[stage]
     feats, mats, hypo = dtu_inputs(H, W, C, D, scale, seed=60 + stage, S=2)
     if not coherent:
@@ -340,38 +365,33 @@ def test_backward_scatter_paths_agree_full_size(dev, stage, coherent):
     hy = hypo.to(dev)
     gvol = torch.randn(1, G, D, H, W, generator=torch.Generator().manual_seed(8)).to(dev)
     grads = {}
-    from deep_reconstruction_with_epipolar_lines_mvster_amd import hotpath
-    seen = []
-    real_call = hotpath._lib.call
-    for route in ("nchw", "nhwc", "nhwc_direct"):
+    for route, layout, mode in (("planar", "nchw", "none"), ("binned", "nhwc", "binned"), ("coefficients", "nhwc", "coefficients"),
+                                ("none", "nhwc", "none")):
         fin = [f.to(dev).requires_grad_(True) for f in feats]
-        hotpath.TILE_SCATTER = route != "nhwc_direct"
-        hotpath._lib.call = lambda name, *a: (seen.append((route, name, a[-3])), real_call(name, *a))[1]
-        try:
-            vol = mv.fused_cost_volume(fin, pose, hy, G, 2.0, layout=route[:4])
+        with backward_workspace(mode):
+            vol = mv.fused_cost_volume(fin, pose, hy, G, 2.0, layout=layout)
             vol.backward(gvol)
-        finally:
-            hotpath.TILE_SCATTER = True
-            hotpath._lib.call = real_call
         grads[route] = [f.grad for f in fin]
-    # the workspace pointer (third argument from the end) is passed exactly when the tiled route applies
-    ws = {r: a for r, n, a in seen if n == "mvster_cost_volume_bwd_ws"}
-    assert (ws["nhwc"] is not None) == (D == 8 and C >= 16) and ws["nhwc_direct"] is None and ws["nchw"] is None
+    assert route_for("binned", 2, 1, C, G, D, H, W) == "binned"
+    assert route_for("full", 2, 1, C, G, D, H, W) == "binned"                                      # the recommendation
+    assert route_for("coefficients", 2, 1, C, G, D, H, W) == ("tile_scatter" if D == 8 else "split_window" if stage == 3 else "dense")
+    assert route_for("none", 2, 1, C, G, D, H, W) == ("split_window" if stage == 3 else "dense")
     tag = "stage%d %s" % (stage + 1, "smooth" if coherent else "random")
     for i in range(len(feats)):
-        close(grads["nhwc"][i], grads["nchw"][i], 2e-5, 1e-7, "%s grad feat%d" % (tag, i))
-        close(grads["nhwc_direct"][i], grads["nchw"][i], 2e-5, 1e-7, "%s grad feat%d (direct)" % (tag, i))
+        for route in ("binned", "coefficients", "none"):
+            close(grads[route][i], grads["planar"][i], 2e-5, 1e-7, "%s grad feat%d (%s)" % (tag, i, route_for(route, 2, 1, C, G, D, H, W)))
 
 
+@pytest.mark.parametrize("mode", ["binned", "coefficients"])
 @pytest.mark.parametrize("C,G,S,B,H,W,Hs,Ws", [(32, 8, 3, 3, 13, 21, 13, 21), (64, 8, 16, 1, 9, 17, 11, 15),
                                                (32, 4, 2, 2, 8, 16, 8, 16), (64, 4, 1, 2, 23, 7, 20, 9),
                                                (16, 4, 3, 2, 19, 26, 19, 26), (16, 8, 2, 1, 8, 8, 10, 12)])
-def test_tiled_scatter_edge_cases_vs_oracle(dev, C, G, S, B, H, W, Hs, Ws):
-    """Two-kernel backward of the coarse stages (D = 8) on awkward shapes: tiles cut by the right / bottom border,
-    source maps of another size, the maximum view count times four channel chunks (grid.z = 64), one view entirely
-    outside the source map, a zero upstream gradient for one hypothesis: gradients of every feature map against the
-    CPU oracle's autograd, and the workspace route must have been the one that ran."""
-    from deep_reconstruction_with_epipolar_lines_mvster_amd import hotpath
+def test_workspace_routes_edge_cases_vs_oracle(dev, C, G, S, B, H, W, Hs, Ws, mode):
+    """The multi-kernel backward routes of the coarse stages (D = 8) on awkward shapes: tiles cut by the right / bottom
+    border, source maps of another size than the reference map, the maximum view count (times four channel chunks in the
+    tiled scatter: grid.z = 64), one view entirely outside the source map, a zero upstream gradient for one hypothesis:
+    gradients of every feature map against the CPU oracle's autograd, for the binned route ("full" workspace) and the
+    round-1 tiled scatter ("coefficients")."""
     D = 8
     g = torch.Generator().manual_seed(C + S + H)
     feats = [0.7 * torch.randn(B, C, H, W, generator=g)] + [0.7 * torch.randn(B, C, Hs, Ws, generator=g) for _ in range(S)]
@@ -386,20 +406,14 @@ def test_tiled_scatter_edge_cases_vs_oracle(dev, C, G, S, B, H, W, Hs, Ws):
     cf = [f.clone().requires_grad_(True) for f in feats]
     (orc.fuse_source_views(cf, mats, hypo, True, G, 2.0, True) * gw).sum().backward()
     gf = [f.to(dev).requires_grad_(True) for f in feats]
-    seen = []
-    real_call = hotpath._lib.call
-    hotpath._lib.call = lambda name, *a: (seen.append((name, a[-3])), real_call(name, *a))[1]
-    try:
+    assert route_for(mode, S, B, C, G, D, H, W, Hs, Ws) == ("binned" if mode == "binned" else "tile_scatter")
+    with backward_workspace(mode):
         vol = mv.fused_cost_volume(gf, mv.stage_poses(mats.to(dev)), hypo.to(dev), G, 2.0)
         (vol * gw.to(dev)).sum().backward()
-    finally:
-        hotpath._lib.call = real_call
-    assert [a for n, a in seen if n == "mvster_cost_volume_bwd_ws"] not in ([], [None])
     for i in range(S + 1):
-        close(gf[i].grad, cf[i].grad, 1e-4, 1e-7, "tiled scatter C%d S%d grad feat%d" % (C, S, i))
+        close(gf[i].grad, cf[i].grad, 1e-4, 1e-7, "%s C%d S%d grad feat%d" % (mode, C, S, i))
     if S >= 2:
         assert float(gf[S].grad.abs().max()) == 0.0
-
 
 # ------------------------------------------------------------------------------------------ B > 1 at full size
 def batched_dtu_inputs(stage, B, S=4, seed=300):
@@ -429,10 +443,10 @@ def test_dtu_stage_batch4_equals_four_single_runs(dev, stage):
     fb = [f.to(dev).requires_grad_(True) for f in feats]
     vol = mv.fused_cost_volume(fb, pose, hypo.to(dev), G, 2.0)
     vol.backward(gvol.to(dev))
-    need = _lib.load().mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC)
-    rid, label, symbol = _lib.bwd_route(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC, need)
+    need = _lib.bwd_workspace(S, B, C, G, D, H, W, H, W, _lib.LAYOUT_NHWC)
+    rid, label, symbol = _lib.bwd_route(S, B, C, G, D, H, W, H, W, _lib.LAYOUT_NHWC, need)
     print("    [route] stage%d B=%d backward: %s (%s)" % (stage + 1, B, label, symbol))
-    assert label == ("tile_scatter" if D == 8 else "split_window")
+    assert label == "binned"
     for b in range(B):
         f1 = [f[b:b + 1].to(dev).requires_grad_(True) for f in feats]
         v1 = mv.fused_cost_volume(f1, pose[b:b + 1].contiguous(), hypo[b:b + 1].to(dev), G, 2.0)
@@ -474,23 +488,27 @@ def test_stage3_lane_split_backward_full_size(dev, G, H, W, coherent):
         g = torch.Generator().manual_seed(G)
         inv = 1 / 935.0 + (1 / 425.0 - 1 / 935.0) * torch.rand(B, 1, H, W, generator=g)
         hypo = (1.0 / (inv + (torch.arange(D).view(1, D, 1, 1) - (D - 1) / 2) * (1 / 425.0 - 1 / 935.0) / 256)).contiguous()
-    need = _lib.load().mvster_cost_volume_bwd_workspace(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC)
-    rid, label, symbol = _lib.bwd_route(S, B, C, G, D, H, W, _lib.LAYOUT_NHWC, need)
-    print("    [route] C16 G%d %dx%d B=2 backward: %s (%s)" % (G, H, W, label, symbol))
+    rid, label, symbol = _lib.bwd_route(S, B, C, G, D, H, W, H, W, _lib.LAYOUT_NHWC, 0)
+    print("    [route] C16 G%d %dx%d B=2 backward without workspace: %s (%s)" % (G, H, W, label, symbol))
     assert label == "split_window" and symbol.startswith("cost_volume_bwd_nhwc_split_kernel<16, %d, 4, 4>" % G)
+    assert route_for("full", S, B, C, G, D, H, W) == "binned"
     pose = mv.stage_poses(mats.to(dev))
     gvol = torch.randn(B, G, D, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
     grads = {}
-    for layout in ("nchw", "nhwc"):
+    for layout, mode in (("nchw", "none"), ("nhwc", "none"), ("nhwc", "binned")):
         fin = [f.to(dev).requires_grad_(True) for f in feats]
-        mv.fused_cost_volume(fin, pose, hypo.to(dev), G, 2.0, layout=layout).backward(gvol)
-        grads[layout] = [f.grad for f in fin]
+        with backward_workspace(mode):
+            mv.fused_cost_volume(fin, pose, hypo.to(dev), G, 2.0, layout=layout).backward(gvol)
+        grads[layout + mode] = [f.grad for f in fin]
     for i in range(S + 1):
-        close(grads["nhwc"][i], grads["nchw"][i], 2e-5, 1e-7, "C16 G%d %s grad feat%d" % (G, "smooth" if coherent else "random", i))
+        tag = "C16 G%d %s grad feat%d" % (G, "smooth" if coherent else "random", i)
+        close(grads["nhwcnone"][i], grads["nchwnone"][i], 2e-5, 1e-7, tag + " (lane split)")
+        close(grads["nhwcbinned"][i], grads["nchwnone"][i], 2e-5, 1e-7, tag + " (binned)")
 
 
+@pytest.mark.parametrize("mode", ["binned", "coefficients"])
 @pytest.mark.parametrize("C,G,zoom", [(32, 8, 0.25), (64, 8, 0.25), (16, 4, 0.25), (32, 8, 1.0)])
-def test_cross_pixel_merge_when_every_step_collides(dev, C, G, zoom):
+def test_cross_pixel_merge_when_every_step_collides(dev, C, G, zoom, mode):
     """Worst case for the cross-pixel merge of the D = 8 backward: fronto-parallel hypotheses (identical depth over the
     whole map) and a source camera zoomed out 4x, so that the footprints of a whole 8 x 8 reference block fall on 2-3
     source pixels -- in the round-1 tiled scatter every step of every tile row has all four lane groups on the same
@@ -508,10 +526,11 @@ def test_cross_pixel_merge_when_every_step_collides(dev, C, G, zoom):
     cf = [f.clone().requires_grad_(True) for f in feats]
     (orc.fuse_source_views(cf, mats, hypo, True, G, 2.0, True) * gw).sum().backward()
     gf = [f.to(dev).requires_grad_(True) for f in feats]
-    vol = mv.fused_cost_volume(gf, mv.stage_poses(mats.to(dev)), hypo.to(dev), G, 2.0)
-    (vol * gw.to(dev)).sum().backward()
+    with backward_workspace(mode):
+        vol = mv.fused_cost_volume(gf, mv.stage_poses(mats.to(dev)), hypo.to(dev), G, 2.0)
+        (vol * gw.to(dev)).sum().backward()
     for i in range(S + 1):
-        close(gf[i].grad, cf[i].grad, 1e-4, 1e-7, "collision tile C%d zoom %.2f grad feat%d" % (C, zoom, i))
+        close(gf[i].grad, cf[i].grad, 1e-4, 1e-7, "collision tile C%d zoom %.2f %s grad feat%d" % (C, zoom, mode, i))
 
 
 def test_identical_views_reduce_to_single_view(dev):

@@ -168,10 +168,12 @@ def test_ddp_wrap_over_rccl_world_size_one():
         loss_ddp = step(wrapped)
         torch.cuda.synchronize()
         assert abs(loss_ddp - loss_plain) <= 1e-4 * abs(loss_plain)
+        largest = max(float(p.grad.abs().max()) for p in plain.parameters())
         for (n, p), (_, q) in zip(plain.named_parameters(), wrapped.module.named_parameters()):
             assert q.grad is not None, n
-            scale = float(p.grad.abs().max()) + 1e-12
-            assert float((p.grad - q.grad).abs().max()) <= 2e-3 * scale + 1e-7, n       # atomics order only
+            # reg.k.prob.bias has an exactly-zero gradient (softmax invariance): rounding noise on both sides
+            scale = max(float(p.grad.abs().max()), 1e-4 * largest)
+            assert float((p.grad - q.grad).abs().max()) <= 2e-3 * scale + 1e-7, n       # summation order only
     finally:
         dist.destroy_process_group()
 

@@ -19,7 +19,10 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--layout", default="nhwc")
     ap.add_argument("--data", default="noise", choices=["noise", "scene"])
+    ap.add_argument("--workspace", default="full", choices=["full", "binned", "coefficients", "none"],
+                    help="scratch offered to the backward = its scatter route (hotpath.BWD_WORKSPACE)")
     args = ap.parse_args()
+    mv.hotpath.BWD_WORKSPACE = args.workspace
     dev = torch.device("cuda:0")
     stages, dv = bench.make_inputs(args.batch, 1234, dev, data=args.data)
     net = mv.stagenet(inverse_depth=True, mono=True, attn_temp=2.0).train()
