@@ -231,8 +231,10 @@ class LaunchTimer:
             a.record()
             orig(name, *args)
             b.record()
-            # mvster_cost_volume_bwd_ws is mvster_cost_volume_bwd plus three trailing workspace arguments
-            name = "mvster_cost_volume_bwd" if name == "mvster_cost_volume_bwd_ws" else name
+            # mvster_cost_volume_bwd_ws is mvster_cost_volume_bwd plus trailing workspace arguments; _fwd_counted is
+            # mvster_cost_volume_fwd plus the tile counters: same leading arguments
+            name = {"mvster_cost_volume_bwd_ws": "mvster_cost_volume_bwd",
+                    "mvster_cost_volume_fwd_counted": "mvster_cost_volume_fwd"}.get(name, name)
             timer.records[(name, timer.shape_key(name, args))].append((a, b))
 
         _lib.call = timed_call

@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmvster_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -25,11 +25,15 @@ PROTOTYPES = {
     "mvster_warp_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_nchw_to_nhwc": [_vp, _vp, _i, _i, _i, _i, _vp],
     "mvster_nhwc_to_nchw": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "mvster_nchw_to_nhwc_many": [_vpp, _vpp, _i, _i, _i, _i, _i, _vp],
+    "mvster_nhwc_to_nchw_many": [_vpp, _vpp, _i, _i, _i, _i, _i, _vp],
     "mvster_cost_volume_fwd": [_vp, _vpp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "mvster_cost_volume_fwd_counted": [_vp, _vpp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp],
+    "mvster_cost_volume_bin_counts": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "mvster_cost_volume_bwd": [_vp, _vp, _vp, _vp, _vpp, _i, _vp, _vp, _vp, _vpp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i,
                                _vp],
     "mvster_cost_volume_bwd_ws": [_vp, _vp, _vp, _vp, _vpp, _i, _vp, _vp, _vp, _vpp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i,
-                                  _vp, _ll, _vp],
+                                  _vp, _ll, _vp, _vp],
     "mvster_cost_volume_bwd_workspace": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "mvster_cost_volume_bwd_route_workspace": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "mvster_cost_volume_bwd_route": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _ll],
@@ -47,7 +51,8 @@ PROTOTYPES = {
     "mvster_schedule_inverse_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
 }
 
-RESTYPES = {"mvster_cost_volume_bwd_workspace": _ll, "mvster_cost_volume_bwd_route_workspace": _ll}      # everything else returns the int status
+RESTYPES = {"mvster_cost_volume_bwd_workspace": _ll, "mvster_cost_volume_bwd_route_workspace": _ll,
+            "mvster_cost_volume_bin_counts": _ll}      # everything else returns the int status
 
 MVSTER_OK = 0
 LAYOUT_NCHW = 0

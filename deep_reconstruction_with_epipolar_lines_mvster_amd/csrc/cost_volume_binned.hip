@@ -35,21 +35,6 @@ struct BinArgs {
     int tiles_per_view, blocks_x;
 };
 
-// Tiles (within one (batch, view) plane) that receive a non-zero tap of one sample: id[k] is the tile of tap k and
-// emit[k] tells whether tap k is the first tap with a non-zero weight in that tile.  At most four tiles.
-__device__ __forceinline__ void footprint_tiles(const Taps& t, const BinGrid& bg, int (&id)[4], bool (&emit)[4]) {
-    bool nz[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        nz[k] = masked_weight(t, k) != 0.0f;                       // in-map taps only: coordinates are >= 0 there
-        id[k] = ((t.iy + (k >> 1)) >> bg.lh) * bg.tiles_x + ((t.ix + (k & 1)) >> bg.lw);
-    }
-    emit[0] = nz[0];
-    emit[1] = nz[1] && !(nz[0] && id[0] == id[1]);
-    emit[2] = nz[2] && !(nz[0] && id[0] == id[2]) && !(nz[1] && id[1] == id[2]);
-    emit[3] = nz[3] && !(nz[0] && id[0] == id[3]) && !(nz[1] && id[1] == id[3]) && !(nz[2] && id[2] == id[3]);
-}
-
 constexpr int kViewBatch = 4;        // views whose tables are live together (their global atomics are in flight together)
 constexpr int kTableLog = 8;         // LDS hash table entries per view: 256 lanes x <= 4 tiles rarely exceed a few dozen keys
 constexpr int kTable = 1 << kTableLog;
@@ -611,28 +596,36 @@ static int launch_bin_items(const BinArgs& ba, int B, int D, int* counters, int*
     return launch_status();
 }
 
+int launch_bin_scan(const int* counts, float* workspace, const BinnedLayout& lay, hipStream_t st) {
+    int* const words = reinterpret_cast<int*>(workspace);
+    const int nbins = (int)lay.nbins, nblocks = grid_for(nbins, kScanBlock);
+    hipLaunchKernelGGL(bin_scan_partials_kernel, dim3(nblocks), dim3(kScanBlock), 0, st, counts, words + lay.partials, nbins);
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL(bin_scan_apply_kernel, dim3(nblocks), dim3(kScanBlock), 0, st, counts, words + lay.partials,
+                       words + lay.offsets, words + lay.cursor, nbins);
+    return launch_status();
+}
+
 int launch_binned_scatter(const float* ref, const float* pose, const float* hypo, const GradPtrs& gsrcs, int B, int C, int G,
-                          int D, const VolumeDims& dm, float* workspace, const BinnedLayout& lay, hipStream_t st) {
+                          int D, const VolumeDims& dm, float* workspace, const BinnedLayout& lay, bool items_filled,
+                          hipStream_t st) {
     const BinGrid bg = bin_grid_for(C, dm.Hs, dm.Ws);
     int* const words = reinterpret_cast<int*>(workspace);
     int* const counts = words + lay.counts;
-    int* const partials = words + lay.partials;
     int* const offsets = words + lay.offsets;
     int* const cursor = words + lay.cursor;
     int* const items = words + lay.items;
     const int nbins = (int)lay.nbins;
-    if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)nbins, st) != hipSuccess) {
-        (void)hipGetLastError();
-        return MVSTER_ERR_LAUNCH;
+    if (!items_filled) {                   // stand-alone counting sort: the forward pass did not count for us
+        if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)nbins, st) != hipSuccess) {
+            (void)hipGetLastError();
+            return MVSTER_ERR_LAUNCH;
+        }
+        BinArgs ba{pose, hypo, dm, bg, bg.tiles_x * bg.tiles_y, 0};
+        if (int rc = launch_bin_items<false>(ba, B, D, counts, nullptr, st)) return rc;
+        if (int rc = launch_bin_scan(counts, workspace, lay, st)) return rc;
+        if (int rc = launch_bin_items<true>(ba, B, D, cursor, items, st)) return rc;
     }
-    BinArgs ba{pose, hypo, dm, bg, bg.tiles_x * bg.tiles_y, 0};
-    if (int rc = launch_bin_items<false>(ba, B, D, counts, nullptr, st)) return rc;
-    const int nblocks = grid_for(nbins, kScanBlock);
-    hipLaunchKernelGGL(bin_scan_partials_kernel, dim3(nblocks), dim3(kScanBlock), 0, st, counts, partials, nbins);
-    if (int rc = launch_status()) return rc;
-    hipLaunchKernelGGL(bin_scan_apply_kernel, dim3(nblocks), dim3(kScanBlock), 0, st, counts, partials, offsets, cursor, nbins);
-    if (int rc = launch_status()) return rc;
-    if (int rc = launch_bin_items<true>(ba, B, D, cursor, items, st)) return rc;
     OwnerArgs oa{workspace + lay.coef, ref, pose, hypo, offsets, items, gsrcs, dm, bg, bg.tiles_x * bg.tiles_y, nbins};
 #define X(C_, G_) \
     if (C == C_ && G == G_) return launch_owner<C_, G_>(oa, D, st);

@@ -83,7 +83,7 @@ cost_volume_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__
             float sg = cor[0][j];
 #pragma unroll
             for (int g = 1; g < G; ++g) sg += cor[g][j];
-            a[j] = sg / dm.temp;
+            a[j] = div_temp(sg, dm);
             m = fmaxf(m, a[j]);
         }
         m = group_max<DL>(m);
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(kBlock)
 cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restrict__ vol,
                             const float* __restrict__ wsum, const float* __restrict__ ref, SrcPtrs srcs,
                             const float* __restrict__ pose, const float* __restrict__ hypo, float* __restrict__ gref,
-                            GradPtrs gsrcs, VolumeDims dm, float* __restrict__ dcor_out) {
+                            GradPtrs gsrcs, VolumeDims dm, float* __restrict__ dcor_out, BinFill bf) {
     constexpr int CPG = C / G;
     constexpr int C4 = C / 4;
     constexpr int DL = D / DPL;
@@ -328,6 +328,17 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
 #pragma unroll
     for (int c = 0; c < C; ++c) dref[c] = 0.0f;
 
+    // DEFER with bf.cursor: second pass of the counting sort (see BinFill).  The slots a view's samples claim with a
+    // returning atomic are consumed one view later, so that the atomic's round trip hides behind the next view's gathers.
+    [[maybe_unused]] int claim_leader[4] = {-1, -1, -1, -1}, claim_rank[4] = {0, 0, 0, 0}, claim_base[4] = {0, 0, 0, 0};
+    [[maybe_unused]] auto write_claimed_items = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (__ballot(claim_leader[k] >= 0) == 0) continue;                      // wave-uniform
+            const int base = __shfl(claim_base[k], max(claim_leader[k], 0), kWave);
+            if (claim_leader[k] >= 0) bf.items[base + claim_rank[k]] = p * D + dl;
+        }
+    };
     for (int s = 0; s < dm.S; ++s) {
         const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C;
         float* __restrict__ gsrcb = gsrcs.p[s] + (size_t)b * HWs * C;
@@ -368,7 +379,7 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
             float sg = cor[0][j];
 #pragma unroll
             for (int g = 1; g < G; ++g) sg += cor[g][j];
-            a[j] = sg / dm.temp;
+            a[j] = div_temp(sg, dm);
             m = fmaxf(m, a[j]);
         }
         m = group_max<DL>(m);
@@ -421,6 +432,24 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
                 dense_scatter<C>(stage[threadIdx.x >> 6], lane, taps[j], dwarp, gsrcb, live);
             }
         }
+        if constexpr (DEFER) {
+            if (bf.cursor != nullptr) {                                              // wave-uniform
+                write_claimed_items();                                               // the previous view's
+                int id[4];
+                bool emit[4];
+                footprint_tiles(taps[0], bf.bg, id, emit);
+                int* __restrict__ cur = bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int count;
+                    wave_group(id[k], live && emit[k], lane, claim_leader[k], claim_rank[k], count);
+                    claim_base[k] = lane == claim_leader[k] ? atomicAdd(cur + id[k], count) : 0;
+                }
+            }
+        }
+    }
+    if constexpr (DEFER) {
+        if (bf.cursor != nullptr) write_claimed_items();
     }
     float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C);
 #pragma unroll
@@ -548,7 +577,7 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
                 for (int i = 1; i < HS; ++i) tot += __shfl(sg, first + i, kWave);
                 sg = tot;
             }
-            a[d] = sg / dm.temp;
+            a[d] = div_temp(sg, dm);
             m = fmaxf(m, a[d]);
         }
         float e[D], sum = 0.0f;
@@ -626,16 +655,28 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
 template <int CPG, int G, int D>
 static int launch_bwd_deferred(const float* gvol, const float* vol, const float* wsum, const float* ref, const SrcPtrs& srcs,
                                const float* pose, const float* hypo, float* gref, const GradPtrs& gsrcs, int B,
-                               VolumeDims dm, int route, float* workspace, const BinnedLayout& lay, hipStream_t st) {
+                               VolumeDims dm, int route, float* workspace, const BinnedLayout& lay, const int* fwd_counts,
+                               hipStream_t st) {
     constexpr int PXB = kBlock / D;
     dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
     float* const dcor = workspace + (route == MVSTER_BWD_ROUTE_BINNED ? lay.coef : 0);
+    BinFill bf{};
+    const bool fill_here = route == MVSTER_BWD_ROUTE_BINNED && fwd_counts != nullptr;
+    if (fill_here) {
+        // the forward pass counted: scan its counts now, let the coefficient kernel claim the slots and write the items
+        if (int rc = launch_bin_scan(fwd_counts, workspace, lay, st)) return rc;
+        int* const words = reinterpret_cast<int*>(workspace);
+        bf.cursor = words + lay.cursor;
+        bf.items = words + lay.items;
+        bf.bg = bin_grid_for(CPG * G, dm.Hs, dm.Ws);
+        bf.tiles_per_view = bf.bg.tiles_x * bf.bg.tiles_y;
+    }
     hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, 1, true>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
-                       ref, srcs, pose, hypo, gref, gsrcs, dm, dcor);
+                       ref, srcs, pose, hypo, gref, gsrcs, dm, dcor, bf);
     if (int rc = launch_status()) return rc;
     if (route == MVSTER_BWD_ROUTE_BINNED)
-        return launch_binned_scatter(ref, pose, hypo, gsrcs, B, CPG * G, G, D, dm, workspace, lay, st);
+        return launch_binned_scatter(ref, pose, hypo, gsrcs, B, CPG * G, G, D, dm, workspace, lay, fill_here, st);
     return launch_tile_scatter(dcor, ref, pose, hypo, gsrcs, B, CPG * G, G, D, dm, st);
 }
 
@@ -660,7 +701,7 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
         // DPL > 1 is only dispatched for D = 4, C <= 16, which returned into the split kernel above
         if constexpr (DPL == 1)
             hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol,
-                               wsum, ref, srcs, pose, hypo, gref, gsrcs, dm, static_cast<float*>(nullptr));
+                               wsum, ref, srcs, pose, hypo, gref, gsrcs, dm, static_cast<float*>(nullptr), BinFill{});
         else
             return MVSTER_ERR_UNSUPPORTED;
     } else
@@ -741,14 +782,15 @@ extern "C" int mvster_cost_volume_bwd(const float* gvol, const float* vol, const
                                       float* gref, float* const* gsrcs, int B, int C, int G, int D, int H, int W,
                                       int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream) {
     return mvster_cost_volume_bwd_ws(gvol, vol, wsum, ref, srcs, S, pose, hypo, gref, gsrcs, B, C, G, D, H, W, Hs, Ws,
-                                     attn_temp, layout, nullptr, 0, stream);
+                                     attn_temp, layout, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int mvster_cost_volume_bwd_ws(const float* gvol, const float* vol, const float* wsum, const float* ref,
                                          const float* const* srcs, int S, const float* pose, const float* hypo,
                                          float* gref, float* const* gsrcs, int B, int C, int G, int D, int H, int W,
                                          int Hs, int Ws, float attn_temp, int layout, float* workspace,
-                                         long long workspace_floats, mvster_stream_t stream) {
+                                         long long workspace_floats, const int32_t* fwd_bin_counts,
+                                         mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(gvol); MVSTER_REQUIRE_PTR(vol); MVSTER_REQUIRE_PTR(wsum); MVSTER_REQUIRE_PTR(ref);
     MVSTER_REQUIRE_PTR(srcs); MVSTER_REQUIRE_PTR(pose); MVSTER_REQUIRE_PTR(hypo); MVSTER_REQUIRE_PTR(gref);
@@ -773,12 +815,13 @@ extern "C" int mvster_cost_volume_bwd_ws(const float* gvol, const float* vol, co
             }
         }
     }
-    VolumeDims dm{H, W, Hs, Ws, S, 0, attn_temp, (float)sqrt((double)C)};
+    VolumeDims dm = make_dims(H, W, Hs, Ws, S, C, attn_temp);
     const int cpg = C / G;
     const bool deferred = route == MVSTER_BWD_ROUTE_BINNED || route == MVSTER_BWD_ROUTE_TILE_SCATTER;
     const bool wide = route == MVSTER_BWD_ROUTE_SPLIT_WINDOW || (route == MVSTER_BWD_ROUTE_PLANAR && pick_pixel_per_lane(B, H * W, C, D));
 #define DEFERRED(CPG_, G_, D_) \
-    return launch_bwd_deferred<CPG_, G_, D_>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, route, workspace, lay, st)
+    return launch_bwd_deferred<CPG_, G_, D_>(gvol, vol, wsum, ref, sp, pose, hypo, gref, gp, B, dm, route, workspace, lay, \
+                                             fwd_bin_counts, st)
 #define X(CPG_, G_)                                                                                                   \
     if (cpg == CPG_ && G == G_) {                                                                                     \
         if (deferred) {                                                                                               \

@@ -19,7 +19,23 @@ struct VolumeDims {
     int H, W, Hs, Ws, S, ntiles;
     float temp;     // attn_temp
     float sqrt_c;   // (float)sqrt(C), the reference divides the view weight by math.sqrt(C)
+    float inv_temp; // 1 / attn_temp when attn_temp is a power of two (x / temp == x * inv_temp bit for bit), else 0
 };
+
+// x / attn_temp as the reference computes it; a power-of-two temperature (the scripts' attn_temp 2) divides exactly by
+// multiplication -- one instruction instead of the ~10 of an IEEE division, in kernels that are VALU-bound.
+#ifdef __HIPCC__
+__device__ __forceinline__ float div_temp(float x, const VolumeDims& dm) {
+    return dm.inv_temp != 0.0f ? x * dm.inv_temp : x / dm.temp;
+}
+#endif
+
+inline VolumeDims make_dims(int H, int W, int Hs, int Ws, int S, int C, float attn_temp) {
+    int e = 0;
+    const float m = frexpf(fabsf(attn_temp), &e);
+    const bool pow2 = m == 0.5f && e > -100 && e < 100;
+    return VolumeDims{H, W, Hs, Ws, S, 0, attn_temp, (float)sqrt((double)C), pow2 ? 1.0f / attn_temp : 0.0f};
+}
 
 // (channels per group, groups) pairs instantiated: C in {8,16,32,64} x G in {4,8}
 #define MVSTER_FOR_SHAPES(X) \
@@ -115,8 +131,80 @@ inline bool binned_layout(int S, int B, int C, int G, int D, int H, int W, int H
     return true;
 }
 
+// fwd_counts: the tile counts the forward pass already took (mvster_cost_volume_fwd_counted), or nullptr: count here.
+// items_filled: the coefficient kernel has already claimed the slots and written the item lists (BinFill below).
 int launch_binned_scatter(const float* ref, const float* pose, const float* hypo, const GradPtrs& gsrcs, int B, int C, int G,
-                          int D, const VolumeDims& dm, float* workspace, const BinnedLayout& lay, hipStream_t st);
+                          int D, const VolumeDims& dm, float* workspace, const BinnedLayout& lay, bool items_filled,
+                          hipStream_t st);
+int launch_bin_scan(const int* counts, float* workspace, const BinnedLayout& lay, hipStream_t st);
+
+#ifdef __HIPCC__
+// ---- the counting sort's two passes, riding on kernels that project every sample anyway ------------------------------
+// Projecting a sample costs ~100 VALU instructions and these kernels are VALU-bound (4 IEEE divisions per projection),
+// so a separate count and a separate fill pass cost 0.6 + 0.85 ms at DTU stage 4.  The forward kernel therefore counts
+// (training mode) and the backward's coefficient kernel fills; both see bitwise the same taps.
+struct BinCount {            // forward: counters[(b*S + s) * tiles_per_view + tile] += 1 per touched tile
+    int* counters;           // nullptr: do not count
+    BinGrid bg;
+    int tiles_per_view;
+};
+struct BinFill {             // backward coefficient kernel: claim slots from cursor[] (starts at the tile offsets), write items
+    int* cursor;             // nullptr: do not fill
+    int* items;
+    BinGrid bg;
+    int tiles_per_view;
+};
+
+// Tiles (within one (batch, view) plane) that receive a non-zero tap of one sample: id[k] is the tile of tap k and
+// emit[k] tells whether tap k is the first tap with a non-zero weight in that tile.  At most four tiles.
+__device__ __forceinline__ void footprint_tiles(const Taps& t, const BinGrid& bg, int (&id)[4], bool (&emit)[4]) {
+    bool nz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        nz[k] = masked_weight(t, k) != 0.0f;                       // in-map taps only: coordinates are >= 0 there
+        id[k] = ((t.iy + (k >> 1)) >> bg.lh) * bg.tiles_x + ((t.ix + (k & 1)) >> bg.lw);
+    }
+    emit[0] = nz[0];
+    emit[1] = nz[1] && !(nz[0] && id[0] == id[1]);
+    emit[2] = nz[2] && !(nz[0] && id[0] == id[2]) && !(nz[1] && id[1] == id[2]);
+    emit[3] = nz[3] && !(nz[0] && id[0] == id[3]) && !(nz[1] && id[1] == id[3]) && !(nz[2] && id[2] == id[3]);
+}
+
+// Groups the lanes of a wave that emit the same tile: leader = lowest such lane, rank = position among them, count = size
+// of the group (leader = -1 for lanes that emit nothing).  The loop runs once per distinct tile in the wave (1-4 at the
+// fine stages); its trip count is wave-uniform.
+__device__ __forceinline__ void wave_group(int tile, bool emit, int lane, int& leader, int& rank, int& count) {
+    leader = -1;
+    rank = 0;
+    count = 0;
+    unsigned long long pend = __ballot(emit);
+    while (pend) {
+        const int l = __ffsll((long long)pend) - 1;
+        const int key = __builtin_amdgcn_readlane(tile, l);
+        const unsigned long long same = __ballot(emit && tile == key);
+        if (emit && tile == key) {
+            leader = l;
+            rank = __popcll(same & ((1ull << lane) - 1ull));
+            count = __popcll(same);
+        }
+        pend &= ~same;
+    }
+}
+
+// forward side: one non-returning int atomic per distinct tile of the wave
+__device__ __forceinline__ void count_sample(const BinCount& bc, int* __restrict__ view_counters, const Taps& t, bool live,
+                                             int lane) {
+    int id[4];
+    bool emit[4];
+    footprint_tiles(t, bc.bg, id, emit);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int leader, rank, count;
+        wave_group(id[k], live && emit[k], lane, leader, rank, count);
+        if (lane == leader) atomicAdd(view_counters + id[k], count);
+    }
+}
+#endif
 
 // Which kernel family the backward entry point runs for a shape (mvster_cost_volume_bwd_route in mvster_hip.h).
 inline int pick_bwd_route(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, int layout,

@@ -86,7 +86,7 @@ cost_volume_fwd_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float*
             float sg = cor[0][j];
 #pragma unroll
             for (int g = 1; g < G; ++g) sg += cor[g][j];
-            a[j] = sg / dm.temp;
+            a[j] = div_temp(sg, dm);
             m = fmaxf(m, a[j]);
         }
         m = group_max<DL>(m);
@@ -126,7 +126,7 @@ template <int C, int G, int D, int DPL>
 __global__ void __launch_bounds__(kBlock)
 cost_volume_fwd_nhwc_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float* __restrict__ pose,
                             const float* __restrict__ hypo, float* __restrict__ vol, float* __restrict__ wsum,
-                            VolumeDims dm) {
+                            VolumeDims dm, BinCount bc) {
     constexpr int CPG = C / G;
     constexpr int C4 = C / 4;
     constexpr int DL = D / DPL;
@@ -170,6 +170,8 @@ cost_volume_fwd_nhwc_kernel(const float* __restrict__ ref, SrcPtrs srcs, const f
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
             const Taps t = project_taps(q, ray, hyp[j], dm.Hs, dm.Ws, half_w, half_h);
+            if (bc.counters != nullptr)          // training: first pass of the backward's counting sort (wave-uniform branch)
+                count_sample(bc, bc.counters + ((size_t)b * dm.S + s) * bc.tiles_per_view, t, live, threadIdx.x & 63);
             const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
             const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
             const float4* __restrict__ p10 = reinterpret_cast<const float4*>(srcb + (size_t)t.o10 * C);
@@ -199,7 +201,7 @@ cost_volume_fwd_nhwc_kernel(const float* __restrict__ ref, SrcPtrs srcs, const f
             float sg = cor[0][j];
 #pragma unroll
             for (int g = 1; g < G; ++g) sg += cor[g][j];
-            a[j] = sg / dm.temp;
+            a[j] = div_temp(sg, dm);
             m = fmaxf(m, a[j]);
         }
         m = group_max<DL>(m);
@@ -230,13 +232,13 @@ cost_volume_fwd_nhwc_kernel(const float* __restrict__ ref, SrcPtrs srcs, const f
 
 template <int CPG, int G, int D, int DPL>
 static int launch_fwd(const float* ref, const SrcPtrs& srcs, const float* pose, const float* hypo, float* vol,
-                      float* wsum, int B, VolumeDims dm, int layout, hipStream_t st) {
+                      float* wsum, int B, VolumeDims dm, int layout, const BinCount& bc, hipStream_t st) {
     constexpr int PXB = kBlock / (D / DPL);
     dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
     if (layout == MVSTER_LAYOUT_NHWC)
         hipLaunchKernelGGL((cost_volume_fwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, ref, srcs,
-                           pose, hypo, vol, wsum, dm);
+                           pose, hypo, vol, wsum, dm, bc);
     else
         hipLaunchKernelGGL((cost_volume_fwd_kernel<CPG, G, D, DPL>), grid, dim3(kBlock), 0, st, ref, srcs, pose, hypo,
                            vol, wsum, dm);
@@ -245,9 +247,24 @@ static int launch_fwd(const float* ref, const SrcPtrs& srcs, const float* pose, 
 
 }  // namespace mvster
 
+extern "C" long long mvster_cost_volume_bin_counts(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws,
+                                                   int layout) {
+    mvster::BinnedLayout lay;
+    if (layout != MVSTER_LAYOUT_NHWC || !mvster::binned_layout(S, B, C, G, D, H, W, Hs, Ws, &lay)) return 0;
+    return lay.nbins;
+}
+
 extern "C" int mvster_cost_volume_fwd(const float* ref, const float* const* srcs, int S, const float* pose,
                                       const float* hypo, float* vol, float* wsum, int B, int C, int G, int D, int H,
                                       int W, int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream) {
+    return mvster_cost_volume_fwd_counted(ref, srcs, S, pose, hypo, vol, wsum, B, C, G, D, H, W, Hs, Ws, attn_temp, layout,
+                                          nullptr, stream);
+}
+
+extern "C" int mvster_cost_volume_fwd_counted(const float* ref, const float* const* srcs, int S, const float* pose,
+                                              const float* hypo, float* vol, float* wsum, int B, int C, int G, int D,
+                                              int H, int W, int Hs, int Ws, float attn_temp, int layout,
+                                              int32_t* bin_counts, mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(ref); MVSTER_REQUIRE_PTR(srcs); MVSTER_REQUIRE_PTR(pose); MVSTER_REQUIRE_PTR(hypo);
     MVSTER_REQUIRE_PTR(vol);
@@ -257,14 +274,26 @@ extern "C" int mvster_cost_volume_fwd(const float* ref, const float* const* srcs
         MVSTER_REQUIRE_PTR(srcs[s]);
         sp.p[s] = srcs[s];
     }
-    VolumeDims dm{H, W, Hs, Ws, S, 0, attn_temp, (float)sqrt((double)C)};
+    VolumeDims dm = make_dims(H, W, Hs, Ws, S, C, attn_temp);
     const hipStream_t st = as_stream(stream);
+    BinCount bc{};
+    if (bin_counts != nullptr) {
+        const long long nbins = mvster_cost_volume_bin_counts(S, B, C, G, D, H, W, Hs, Ws, layout);
+        if (nbins <= 0) return MVSTER_ERR_UNSUPPORTED;
+        if (hipMemsetAsync(bin_counts, 0, sizeof(int) * (size_t)nbins, st) != hipSuccess) {
+            (void)hipGetLastError();
+            return MVSTER_ERR_LAUNCH;
+        }
+        bc.counters = bin_counts;
+        bc.bg = bin_grid_for(C, Hs, Ws);
+        bc.tiles_per_view = bc.bg.tiles_x * bc.bg.tiles_y;
+    }
     const int cpg = C / G;
 #define X(CPG_, G_)                                                                                          \
     if (cpg == CPG_ && G == G_) {                                                                            \
-        if (D == 4) return launch_fwd<CPG_, G_, 4, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st);            \
-        if (D == 8) return launch_fwd<CPG_, G_, 8, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st);            \
-        if (D == 16) return launch_fwd<CPG_, G_, 16, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, st);          \
+        if (D == 4) return launch_fwd<CPG_, G_, 4, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, bc, st);        \
+        if (D == 8) return launch_fwd<CPG_, G_, 8, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, bc, st);        \
+        if (D == 16) return launch_fwd<CPG_, G_, 16, 1>(ref, sp, pose, hypo, vol, wsum, B, dm, layout, bc, st);      \
     }
     MVSTER_FOR_SHAPES(X)
 #undef X

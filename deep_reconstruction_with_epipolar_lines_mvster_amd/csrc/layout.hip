@@ -8,9 +8,19 @@
 
 namespace mvster {
 
+// Several maps of one shape in one launch (blockIdx.z picks the map): a stage converts its N feature maps -- and the N
+// gradients on the way back -- with one launch each instead of N.
+constexpr int kMaxMaps = MVSTER_MAX_SRC_VIEWS + 1;
+struct MapPtrs {
+    const float* src[kMaxMaps];
+    float* dst[kMaxMaps];
+};
+
 template <int C4T>   // C4T > 0: C/4 known at compile time (registers); 0: runtime C (C % 4 == 0)
 __global__ void __launch_bounds__(kBlock)
-nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
+nchw_to_nhwc_kernel(MapPtrs maps, int C, int HW) {
+    const float* __restrict__ src = maps.src[blockIdx.z];
+    float* __restrict__ dst = maps.dst[blockIdx.z];
     const int b = blockIdx.y;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= HW) return;
@@ -42,7 +52,9 @@ nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int 
 
 template <int C4T>
 __global__ void __launch_bounds__(kBlock)
-nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
+nhwc_to_nchw_kernel(MapPtrs maps, int C, int HW) {
+    const float* __restrict__ src = maps.src[blockIdx.z];
+    float* __restrict__ dst = maps.dst[blockIdx.z];
     const int b = blockIdx.y;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= HW) return;
@@ -80,28 +92,56 @@ static int check_layout(const void* a, const void* b, int B, int C, int H, int W
 
 }  // namespace mvster
 
-#define MVSTER_LAYOUT_DISPATCH(KERNEL)                                                                     \
-    switch (C) {                                                                                           \
-        case 8: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(kBlock), 0, st, src, dst, C, H * W); break;     \
-        case 16: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(kBlock), 0, st, src, dst, C, H * W); break;    \
-        case 32: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(kBlock), 0, st, src, dst, C, H * W); break;    \
-        default: hipLaunchKernelGGL((KERNEL<0>), grid, dim3(kBlock), 0, st, src, dst, C, H * W); break;    \
+#define MVSTER_LAYOUT_DISPATCH(KERNEL)                                                                 \
+    switch (C) {                                                                                       \
+        case 8: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(kBlock), 0, st, maps, C, H * W); break;     \
+        case 16: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(kBlock), 0, st, maps, C, H * W); break;    \
+        case 32: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(kBlock), 0, st, maps, C, H * W); break;    \
+        default: hipLaunchKernelGGL((KERNEL<0>), grid, dim3(kBlock), 0, st, maps, C, H * W); break;    \
     }
 
-extern "C" int mvster_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, mvster_stream_t stream) {
+namespace mvster {
+static int gather_maps(const float* const* srcs, float* const* dsts, int N, MapPtrs* maps) {
+    MVSTER_REQUIRE_PTR(srcs); MVSTER_REQUIRE_PTR(dsts);
+    MVSTER_REQUIRE_SHAPE(N > 0);
+    if (N > kMaxMaps) return MVSTER_ERR_UNSUPPORTED;
+    for (int i = 0; i < N; ++i) {
+        MVSTER_REQUIRE_PTR(srcs[i]); MVSTER_REQUIRE_PTR(dsts[i]);
+        maps->src[i] = srcs[i];
+        maps->dst[i] = dsts[i];
+    }
+    return MVSTER_OK;
+}
+}  // namespace mvster
+
+extern "C" int mvster_nchw_to_nhwc_many(const float* const* srcs, float* const* dsts, int N, int B, int C, int H, int W,
+                                        mvster_stream_t stream) {
     using namespace mvster;
-    if (int rc = check_layout(src, dst, B, C, H, W)) return rc;
-    dim3 grid(grid_for((long long)H * W, kBlock), B);
+    MapPtrs maps{};
+    if (int rc = gather_maps(srcs, dsts, N, &maps)) return rc;
+    if (int rc = check_layout(maps.src[0], maps.dst[0], B, C, H, W)) return rc;
+    dim3 grid(grid_for((long long)H * W, kBlock), B, N);
     const hipStream_t st = as_stream(stream);
     MVSTER_LAYOUT_DISPATCH(nchw_to_nhwc_kernel)
     return launch_status();
 }
 
-extern "C" int mvster_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, mvster_stream_t stream) {
+extern "C" int mvster_nhwc_to_nchw_many(const float* const* srcs, float* const* dsts, int N, int B, int C, int H, int W,
+                                        mvster_stream_t stream) {
     using namespace mvster;
-    if (int rc = check_layout(src, dst, B, C, H, W)) return rc;
-    dim3 grid(grid_for((long long)H * W, kBlock), B);
+    MapPtrs maps{};
+    if (int rc = gather_maps(srcs, dsts, N, &maps)) return rc;
+    if (int rc = check_layout(maps.src[0], maps.dst[0], B, C, H, W)) return rc;
+    dim3 grid(grid_for((long long)H * W, kBlock), B, N);
     const hipStream_t st = as_stream(stream);
     MVSTER_LAYOUT_DISPATCH(nhwc_to_nchw_kernel)
     return launch_status();
+}
+
+extern "C" int mvster_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, mvster_stream_t stream) {
+    return mvster_nchw_to_nhwc_many(&src, &dst, 1, B, C, H, W, stream);
+}
+
+extern "C" int mvster_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, mvster_stream_t stream) {
+    return mvster_nhwc_to_nchw_many(&src, &dst, 1, B, C, H, W, stream);
 }

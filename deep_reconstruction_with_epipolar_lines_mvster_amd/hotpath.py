@@ -156,6 +156,31 @@ def to_channels_last(t):
     return out
 
 
+def _convert_many(tensors, to_nhwc):
+    """Layout-convert several [B,C,H,W] fp32 tensors in as few launches as their shapes allow (one per distinct shape).
+    to_nhwc: NCHW-contiguous inputs -> channels_last copies; else channels_last inputs -> NCHW-contiguous copies."""
+    outs = [None] * len(tensors)
+    groups = {}
+    for i, t in enumerate(tensors):
+        groups.setdefault(tuple(t.shape), []).append(i)
+    for shape, idx in groups.items():
+        B, C, H, W = shape
+        for lo in range(0, len(idx), _MAX_SRC + 1):
+            part = idx[lo:lo + _MAX_SRC + 1]
+            srcs = [tensors[i] for i in part]
+            fmt = torch.channels_last if to_nhwc else torch.contiguous_format
+            dsts = [torch.empty(shape, dtype=torch.float32, device=srcs[0].device, memory_format=fmt) for _ in part]
+            sp, skeep = _lib.ptr_array(srcs)
+            dp, dkeep = _lib.ptr_array(dsts)
+            with _on(srcs[0].device):
+                _lib.call("mvster_nchw_to_nhwc_many" if to_nhwc else "mvster_nhwc_to_nchw_many", sp, dp, len(part), B, C, H, W,
+                          _stream(srcs[0].device))
+            del skeep, dkeep
+            for i, d in zip(part, dsts):
+                outs[i] = d
+    return outs
+
+
 def to_planar(t):
     """channels_last [B,C,H,W] tensor -> NCHW-contiguous copy."""
     if t.is_contiguous():
@@ -172,6 +197,7 @@ def to_planar(t):
 # "coefficients" = only the per-hypothesis coefficients (round-1 tiled scatter where it applies), "none" = the plain
 # atomic routes.  Tests and tools switch it to compare the routes; product code leaves it alone.
 BWD_WORKSPACE = "full"
+COUNT_IN_FORWARD = True     # training forward also counts the samples per destination tile for the binned backward
 
 
 class _FusedCostVolume(torch.autograd.Function):
@@ -188,19 +214,34 @@ class _FusedCostVolume(torch.autograd.Function):
         feats = (ref,) + tuple(srcs)
         if layout == _lib.LAYOUT_NHWC:
             was_cl = [_is_channels_last(f) for f in feats]
-            feats = tuple(to_channels_last(f) for f in feats)
+            todo = [i for i, f in enumerate(feats) if not f.is_contiguous(memory_format=torch.channels_last)]
+            if todo:                                        # all planar maps of the stage in one launch
+                done = _convert_many([feats[i].contiguous() for i in todo], to_nhwc=True)
+                feats = list(feats)
+                for i, d in zip(todo, done):
+                    feats[i] = d
+                feats = tuple(feats)
         else:
             was_cl = [False] * len(feats)
             feats = tuple(f.contiguous() for f in feats)
         vol = torch.empty(B, G, D, H, W, dtype=torch.float32, device=ref.device)
         wsum = torch.empty(B, D, H, W, dtype=torch.float32, device=ref.device)
+        # training: the forward kernel also takes the count pass of the binned backward's counting sort (it has every
+        # projection at hand); the counters travel to the backward through ctx
+        counts = None
+        if COUNT_IN_FORWARD and BWD_WORKSPACE in ("full", "binned") and any(ctx.needs_input_grad[5:]):
+            nb = _lib.load().mvster_cost_volume_bin_counts(S, B, C, G, D, H, W, Hs, Ws, layout)
+            if nb > 0 and (BWD_WORKSPACE == "binned" or _lib.bwd_workspace(S, B, C, G, D, H, W, Hs, Ws, layout) ==
+                           _lib.bwd_workspace(S, B, C, G, D, H, W, Hs, Ws, layout, route="binned")):
+                counts = torch.empty(nb, dtype=torch.int32, device=ref.device)
         pp, keep = _lib.ptr_array(feats[1:])
         with _on(ref.device):
-            _lib.call("mvster_cost_volume_fwd", feats[0].data_ptr(), pp, S, pose.data_ptr(), hypo.data_ptr(),
+            _lib.call("mvster_cost_volume_fwd_counted", feats[0].data_ptr(), pp, S, pose.data_ptr(), hypo.data_ptr(),
                       vol.data_ptr(), wsum.data_ptr(), B, C, G, D, H, W, Hs, Ws, float(attn_temp), layout,
-                      _stream(ref.device))
+                      counts.data_ptr() if counts is not None else None, _stream(ref.device))
         del keep
         ctx.save_for_backward(pose, hypo, vol, wsum, *feats)
+        ctx.bin_counts = counts
         ctx.cfg = (float(attn_temp), int(G), int(layout), was_cl)
         return vol
 
@@ -232,10 +273,14 @@ class _FusedCostVolume(torch.autograd.Function):
         with _on(ref.device):
             _lib.call("mvster_cost_volume_bwd_ws", gvol.data_ptr(), vol.data_ptr(), wsum.data_ptr(), ref.data_ptr(), pp, S,
                       pose.data_ptr(), hypo.data_ptr(), grads[0].data_ptr(), gp, B, C, G, D, H, W, Hs, Ws, attn_temp,
-                      layout, ws.data_ptr() if ws is not None else None, need, _stream(ref.device))
+                      layout, ws.data_ptr() if ws is not None else None, need,
+                      ctx.bin_counts.data_ptr() if ctx.bin_counts is not None else None, _stream(ref.device))
         del keep, gkeep, ws
         if layout == _lib.LAYOUT_NHWC:
-            grads = [g if cl else to_planar(g) for g, cl in zip(grads, was_cl)]
+            todo = [i for i, cl in enumerate(was_cl) if not cl and not grads[i].is_contiguous()]
+            if todo:                                        # gradients of the planar leaves, one launch
+                for i, d in zip(todo, _convert_many([grads[i] for i in todo], to_nhwc=False)):
+                    grads[i] = d
         return (None, None, None, None, None) + tuple(grads)
 
 

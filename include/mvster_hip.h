@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MVSTER_ABI_VERSION 2
+#define MVSTER_ABI_VERSION 3
 
 #define MVSTER_OK 0
 #define MVSTER_ERR_NULL_POINTER 1   /* a required pointer argument is NULL                     */
@@ -72,6 +72,12 @@ int mvster_stage_poses(const float *proj_matrices, float *pose, int B, int N, mv
  */
 int mvster_nchw_to_nhwc(const float *src, float *dst, int B, int C, int H, int W, mvster_stream_t stream);
 int mvster_nhwc_to_nchw(const float *src, float *dst, int B, int C, int H, int W, mvster_stream_t stream);
+/* N maps of one shape in ONE launch (N <= MVSTER_MAX_SRC_VIEWS + 1): srcs / dsts are host arrays of N device pointers.
+ * A stage converts its reference + source feature maps, and their gradients on the way back, with one launch each. */
+int mvster_nchw_to_nhwc_many(const float *const *srcs, float *const *dsts, int N, int B, int C, int H, int W,
+                             mvster_stream_t stream);
+int mvster_nhwc_to_nchw_many(const float *const *srcs, float *const *dsts, int N, int B, int C, int H, int W,
+                             mvster_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * A1  homo_warping: bilinear (zeros padding, align_corners=True) gather of src features at the
@@ -105,6 +111,19 @@ int mvster_cost_volume_fwd(const float *ref, const float *const *srcs, int S, co
                            const float *hypo, float *vol, float *wsum, int B, int C, int G, int D, int H,
                            int W, int Hs, int Ws, float attn_temp, int layout, mvster_stream_t stream);
 
+/* A2 in training mode: the same forward, which additionally takes the FIRST pass of the binned backward's counting sort
+ * while it has every sample's projection at hand: bin_counts[mvster_cost_volume_bin_counts(...)] (int32, zeroed by the
+ * call) receives, per (batch, view, tile of the source map), the number of (pixel, hypothesis) samples whose 2x2
+ * footprint touches the tile.  Hand it to mvster_cost_volume_bwd_ws as fwd_bin_counts.  bin_counts == NULL: plain
+ * mvster_cost_volume_fwd.  Channels-last only (MVSTER_ERR_UNSUPPORTED otherwise).
+ *   mvster_cost_volume_bin_counts : number of int32 counters for this shape, 0 when the binned route does not exist.
+ */
+long long mvster_cost_volume_bin_counts(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, int layout);
+int mvster_cost_volume_fwd_counted(const float *ref, const float *const *srcs, int S, const float *pose,
+                                   const float *hypo, float *vol, float *wsum, int B, int C, int G, int D, int H,
+                                   int W, int Hs, int Ws, float attn_temp, int layout, int32_t *bin_counts,
+                                   mvster_stream_t stream);
+
 /* A3  gradient of mvster_cost_volume_fwd w.r.t. every feature map (recompute-based).
  *   gvol : [B,G,D,H,W]   vol, wsum : the forward outputs
  *   gref : [B,C,H,W] (overwritten)   gsrcs : host array of S device pointers, each [B,C,Hs,Ws]
@@ -125,6 +144,8 @@ int mvster_cost_volume_bwd(const float *gvol, const float *vol, const float *wsu
  * coefficients [B,S,H*W,D,G] and the sort's arrays (worst case 4 tile entries per sample): see DESIGN.md section 3.
  * A workspace of only B*S*H*W*D*G words selects the round-1 TILE_SCATTER route for D = 8, C >= 16;
  * workspace == NULL or anything shorter: identical to mvster_cost_volume_bwd.  The library never allocates.
+ * fwd_bin_counts: the counters mvster_cost_volume_fwd_counted filled for the same inputs, or NULL.  With them the binned
+ * route skips its own count pass and the coefficient kernel also does the sort's fill pass (no extra projection passes).
  *   mvster_cost_volume_bwd_workspace : words the RECOMMENDED (fastest measured) route of this shape wants, 0 when it
  *       wants none.  The entry point takes the binned route whenever the workspace is large enough for it, the
  *       recommendation only decides what the query asks for (C = 8: nothing, the lane-split window kernel is faster).
@@ -139,7 +160,7 @@ int mvster_cost_volume_bwd_ws(const float *gvol, const float *vol, const float *
                               const float *const *srcs, int S, const float *pose, const float *hypo,
                               float *gref, float *const *gsrcs, int B, int C, int G, int D, int H, int W,
                               int Hs, int Ws, float attn_temp, int layout, float *workspace,
-                              long long workspace_floats, mvster_stream_t stream);
+                              long long workspace_floats, const int32_t *fwd_bin_counts, mvster_stream_t stream);
 
 /* Which kernel family mvster_cost_volume_bwd_ws runs for a shape and workspace size (so that tests and the
  * benchmark can state -- and assert -- the route instead of mirroring the dispatch rules).

@@ -135,7 +135,7 @@ def test_backward_workspace_and_route_queries(lib):
         assert q(*args) == 0
     # the _ws entry point validates like the plain one before touching the device
     rc = lib.mvster_cost_volume_bwd_ws(None, None, None, None, None, 1, None, None, None, None, 1, 32, 8, 8, 4, 4, 4, 4,
-                                       2.0, _lib.LAYOUT_NHWC, None, 0, None)
+                                       2.0, _lib.LAYOUT_NHWC, None, 0, None, None)
     assert rc == 1          # MVSTER_ERR_NULL_POINTER
 
 

@@ -56,16 +56,18 @@ def close(actual, expected, rel, abs_=1e-6, what="", exact=None):
 class backward_workspace:
     """Select the scratch the backward may use (hotpath.BWD_WORKSPACE) -- and with it the scatter route -- for a block."""
 
-    def __init__(self, mode):
+    def __init__(self, mode, count_in_forward=True):
         self.mode = mode
+        self.count_in_forward = count_in_forward
 
     def __enter__(self):
         from deep_reconstruction_with_epipolar_lines_mvster_amd import hotpath
-        self.prev, hotpath.BWD_WORKSPACE = hotpath.BWD_WORKSPACE, self.mode
+        self.prev = (hotpath.BWD_WORKSPACE, hotpath.COUNT_IN_FORWARD)
+        hotpath.BWD_WORKSPACE, hotpath.COUNT_IN_FORWARD = self.mode, self.count_in_forward
 
     def __exit__(self, *exc):
         from deep_reconstruction_with_epipolar_lines_mvster_amd import hotpath
-        hotpath.BWD_WORKSPACE = self.prev
+        hotpath.BWD_WORKSPACE, hotpath.COUNT_IN_FORWARD = self.prev
 
 
 def route_for(mode, S, B, C, G, D, H, W, Hs=None, Ws=None):
@@ -365,10 +367,12 @@ def test_backward_scatter_paths_agree_full_size(dev, stage, coherent):
     hy = hypo.to(dev)
     gvol = torch.randn(1, G, D, H, W, generator=torch.Generator().manual_seed(8)).to(dev)
     grads = {}
-    for route, layout, mode in (("planar", "nchw", "none"), ("binned", "nhwc", "binned"), ("coefficients", "nhwc", "coefficients"),
-                                ("none", "nhwc", "none")):
+    for route, layout, mode in (("planar", "nchw", "none"), ("binned", "nhwc", "binned"), ("binned_alone", "nhwc", "binned"),
+                                ("coefficients", "nhwc", "coefficients"), ("none", "nhwc", "none")):
         fin = [f.to(dev).requires_grad_(True) for f in feats]
-        with backward_workspace(mode):
+        # "binned": the forward counts the samples per tile and the coefficient kernel fills the lists;
+        # "binned_alone": the backward runs its own count and fill kernels (a forward that did not count)
+        with backward_workspace(mode, count_in_forward=route != "binned_alone"):
             vol = mv.fused_cost_volume(fin, pose, hy, G, 2.0, layout=layout)
             vol.backward(gvol)
         grads[route] = [f.grad for f in fin]
@@ -378,11 +382,12 @@ def test_backward_scatter_paths_agree_full_size(dev, stage, coherent):
     assert route_for("none", 2, 1, C, G, D, H, W) == ("split_window" if stage == 3 else "dense")
     tag = "stage%d %s" % (stage + 1, "smooth" if coherent else "random")
     for i in range(len(feats)):
-        for route in ("binned", "coefficients", "none"):
-            close(grads[route][i], grads["planar"][i], 2e-5, 1e-7, "%s grad feat%d (%s)" % (tag, i, route_for(route, 2, 1, C, G, D, H, W)))
+        for route in ("binned", "binned_alone", "coefficients", "none"):
+            close(grads[route][i], grads["planar"][i], 2e-5, 1e-7,
+                  "%s grad feat%d (%s)" % (tag, i, route if route == "binned_alone" else route_for(route, 2, 1, C, G, D, H, W)))
 
 
-@pytest.mark.parametrize("mode", ["binned", "coefficients"])
+@pytest.mark.parametrize("mode", ["binned", "binned_alone", "coefficients"])
 @pytest.mark.parametrize("C,G,S,B,H,W,Hs,Ws", [(32, 8, 3, 3, 13, 21, 13, 21), (64, 8, 16, 1, 9, 17, 11, 15),
                                                (32, 4, 2, 2, 8, 16, 8, 16), (64, 4, 1, 2, 23, 7, 20, 9),
                                                (16, 4, 3, 2, 19, 26, 19, 26), (16, 8, 2, 1, 8, 8, 10, 12)])
@@ -406,8 +411,10 @@ def test_workspace_routes_edge_cases_vs_oracle(dev, C, G, S, B, H, W, Hs, Ws, mo
     cf = [f.clone().requires_grad_(True) for f in feats]
     (orc.fuse_source_views(cf, mats, hypo, True, G, 2.0, True) * gw).sum().backward()
     gf = [f.to(dev).requires_grad_(True) for f in feats]
+    alone = mode == "binned_alone"
+    mode = "binned" if alone else mode
     assert route_for(mode, S, B, C, G, D, H, W, Hs, Ws) == ("binned" if mode == "binned" else "tile_scatter")
-    with backward_workspace(mode):
+    with backward_workspace(mode, count_in_forward=not alone):
         vol = mv.fused_cost_volume(gf, mv.stage_poses(mats.to(dev)), hypo.to(dev), G, 2.0)
         (vol * gw.to(dev)).sum().backward()
     for i in range(S + 1):

@@ -21,8 +21,10 @@ def main():
     ap.add_argument("--data", default="noise", choices=["noise", "scene"])
     ap.add_argument("--workspace", default="full", choices=["full", "binned", "coefficients", "none"],
                     help="scratch offered to the backward = its scatter route (hotpath.BWD_WORKSPACE)")
+    ap.add_argument("--count-in-backward", action="store_true", help="stand-alone count / fill kernels instead of the fused ones")
     args = ap.parse_args()
     mv.hotpath.BWD_WORKSPACE = args.workspace
+    mv.hotpath.COUNT_IN_FORWARD = not args.count_in_backward
     dev = torch.device("cuda:0")
     stages, dv = bench.make_inputs(args.batch, 1234, dev, data=args.data)
     net = mv.stagenet(inverse_depth=True, mono=True, attn_temp=2.0).train()
