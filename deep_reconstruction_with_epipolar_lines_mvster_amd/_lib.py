@@ -8,7 +8,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmvster_hip.so")
+# MVSTER_LIB_PATH: load another build of the same library (tuning sweeps); never a different implementation
+LIB_PATH = os.environ.get("MVSTER_LIB_PATH") or os.path.join(_HERE, "csrc", "libmvster_hip.so")
 ABI_VERSION = 3
 
 _vp = ctypes.c_void_p

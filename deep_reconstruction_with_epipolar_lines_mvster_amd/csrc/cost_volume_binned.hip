@@ -205,8 +205,8 @@ struct OwnerTile {
     static constexpr int BW = TW + 1, BH = TH + 1;                 // source pixels that can hold the upper-left tap of a sample
     static constexpr int NCELL = BW * BH;                          // touching the tile: one column / row of halo
     static constexpr int NT = ((NCELL + kWave - 1) / kWave) * kWave;   // one lane per such pixel: 192 / 192 / 192 / 128
-    static constexpr int KPT = C == 8 ? 4 : 8;                     // samples a lane sorts per chunk
-    static constexpr int CHUNK = NT * KPT;                         // 768 (48 B each in LDS) / 1536 / 1536 / 1024 samples (16 B each)
+    static constexpr int KPT = C == 8 ? MVSTER_C8_KPT : MVSTER_OWNER_KPT;                     // samples a lane sorts per chunk
+    static constexpr int CHUNK = NT * KPT;                         // 384 (48 B each in LDS) / 1536 / 1536 / 1024 samples (16 B each)
 };
 
 struct __attribute__((aligned(16))) SampleRec {

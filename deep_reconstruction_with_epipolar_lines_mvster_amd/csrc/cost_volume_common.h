@@ -79,7 +79,16 @@ struct BinGrid {
 
 // tile area x C x 4 B of LDS for the tile image: 4 / 8 / 16 / 16 KB per workgroup
 template <int C> struct BinTile;
-template <> struct BinTile<8> { static constexpr int kLw = 4, kLh = 3; };     // 16 x 8
+#ifndef MVSTER_C8_LW          // tuning hooks (tools/probes/owner_sweep.sh builds variants); the defaults are the measured best
+#define MVSTER_C8_LW 4
+#endif
+#ifndef MVSTER_C8_KPT          // swept on MI355X, DTU stage 4, B = 4, noise / scene, ms per backward:
+#define MVSTER_C8_KPT 2        //   16x8 tile: KPT 1 4.96/4.30, 2 4.45/3.73, 3 4.57/3.93, 4 4.91/4.01, 6 5.76/4.84
+#endif                         //   8x8: KPT 2 4.62/3.86, 3 4.85/3.85, 4 5.04/4.11;  32x8: KPT 2 5.45/4.51, 3 7.03/6.02
+#ifndef MVSTER_OWNER_KPT
+#define MVSTER_OWNER_KPT 8
+#endif
+template <> struct BinTile<8> { static constexpr int kLw = MVSTER_C8_LW, kLh = 3; };     // 16 x 8
 template <> struct BinTile<16> { static constexpr int kLw = 4, kLh = 3; };    // 16 x 8
 template <> struct BinTile<32> { static constexpr int kLw = 4, kLh = 3; };    // 16 x 8
 template <> struct BinTile<64> { static constexpr int kLw = 3, kLh = 3; };    //  8 x 8
