@@ -47,6 +47,8 @@ PROTOTYPES = {
     "mvster_bn_train_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvster_bn_train_fwd_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _f, _i, _vp],
     "mvster_bn_train_bwd_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    "mvster_fpn_merge_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvster_fpn_merge_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_geometric_consistency": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "mvster_init_range": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_schedule_inverse_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

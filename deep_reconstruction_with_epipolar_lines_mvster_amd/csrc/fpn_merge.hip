@@ -1,0 +1,243 @@
+// F3  top-down merge of the feature pyramid, one fused operator each way:
+//        y = bilinear_x2(feat, align_corners=True) + conv1x1(skip; weight, bias)
+// replaces: `F.interpolate(intra_feat, scale_factor=2, mode="bilinear", align_corners=True) + self.innerK(convK)` in
+// FPN4.forward (models/mvs4net_utils.py:490-505), i.e. ATen's upsample kernel, a MIOpen/rocBLAS 1x1 convolution, an
+// element-wise add -- and, backwards, ATen's atomic upsample backward, two convolution-gradient kernels with their
+// layout transposes and a bias reduction.  At DTU resolution the merged map has 64 channels at FULL resolution
+// (472 MB per view): every one of those operators is a pass over it.  Here the forward writes it once and the backward
+// reads its gradient three times (skip gradient, weight/bias gradient, transposed upsample), all streaming.
+//
+// Layout: NCHW planes, one lane per pixel, so every access to a channel plane is a coalesced row segment.
+#include "mvster_device.h"
+#include "mvster_host.h"
+
+namespace mvster {
+
+constexpr int kMaxTop = 64;       // output channels (8 * base_channels)
+constexpr int kMaxSkip = 32;      // lateral input channels
+
+// PyTorch's align_corners=True source index: src = dst * (in - 1) / (out - 1) in float; i0 = (int)src,
+// i1 = i0 + (i0 < in - 1), lambda1 = src - i0, lambda0 = 1 - lambda1   (aten/src/ATen/native/UpSample.h)
+struct Lerp {
+    int i0, i1;
+    float l0, l1;
+};
+
+__device__ __forceinline__ Lerp source_index(int dst, float scale, int in) {
+    const float src = scale * (float)dst;
+    Lerp r;
+    r.i0 = (int)src;
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.0f - r.l1;
+    return r;
+}
+
+struct MergeDims {
+    int N, Ct, Cs, h, w, H, W;    // feat [N,Ct,h,w], skip [N,Cs,H,W], y [N,Ct,H,W] with H = 2h, W = 2w
+    float sy, sx;                  // (h - 1) / (H - 1), (w - 1) / (W - 1)
+};
+
+template <int CS>
+__global__ void __launch_bounds__(kBlock)
+fpn_merge_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ skip, const float* __restrict__ weight,
+                     const float* __restrict__ bias, float* __restrict__ y, MergeDims dm) {
+    __shared__ float wl[kMaxTop * CS], bl[kMaxTop];
+    for (int i = threadIdx.x; i < dm.Ct * CS; i += kBlock) wl[i] = weight[i];
+    for (int i = threadIdx.x; i < dm.Ct; i += kBlock) bl[i] = bias != nullptr ? bias[i] : 0.0f;
+    __syncthreads();
+    const int n = blockIdx.y;
+    const int HW = dm.H * dm.W, hw = dm.h * dm.w;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= HW) return;
+    const int yy = p / dm.W, xx = p - yy * dm.W;
+    const Lerp ly = source_index(yy, dm.sy, dm.h), lx = source_index(xx, dm.sx, dm.w);
+    const int o00 = ly.i0 * dm.w + lx.i0, o01 = ly.i0 * dm.w + lx.i1, o10 = ly.i1 * dm.w + lx.i0, o11 = ly.i1 * dm.w + lx.i1;
+    float sk[CS];
+#pragma unroll
+    for (int ci = 0; ci < CS; ++ci) sk[ci] = skip[((size_t)n * CS + ci) * HW + p];
+    const float* __restrict__ fb = feat + (size_t)n * dm.Ct * hw;
+    float* __restrict__ yb = y + (size_t)n * dm.Ct * HW + p;
+    for (int c = 0; c < dm.Ct; ++c) {
+        const float* __restrict__ f = fb + (size_t)c * hw;
+        const float up = ly.l0 * (lx.l0 * f[o00] + lx.l1 * f[o01]) + ly.l1 * (lx.l0 * f[o10] + lx.l1 * f[o11]);
+        float lat = bl[c];
+#pragma unroll
+        for (int ci = 0; ci < CS; ++ci) lat = fmaf(wl[c * CS + ci], sk[ci], lat);
+        yb[(size_t)c * HW] = up + lat;
+    }
+}
+
+// dskip[ci] = sum_c weight[c,ci] * dy[c]   (the 1x1 convolution's input gradient)
+template <int CS>
+__global__ void __launch_bounds__(kBlock)
+fpn_merge_bwd_skip_kernel(const float* __restrict__ dy, const float* __restrict__ weight, float* __restrict__ dskip,
+                          MergeDims dm) {
+    __shared__ float wl[kMaxTop * CS];
+    for (int i = threadIdx.x; i < dm.Ct * CS; i += kBlock) wl[i] = weight[i];
+    __syncthreads();
+    const int n = blockIdx.y;
+    const int HW = dm.H * dm.W;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= HW) return;
+    float acc[CS];
+#pragma unroll
+    for (int ci = 0; ci < CS; ++ci) acc[ci] = 0.0f;
+    const float* __restrict__ d = dy + (size_t)n * dm.Ct * HW + p;
+    for (int c = 0; c < dm.Ct; ++c) {
+        const float g = d[(size_t)c * HW];
+#pragma unroll
+        for (int ci = 0; ci < CS; ++ci) acc[ci] = fmaf(wl[c * CS + ci], g, acc[ci]);
+    }
+#pragma unroll
+    for (int ci = 0; ci < CS; ++ci) dskip[((size_t)n * CS + ci) * HW + p] = acc[ci];
+}
+
+// dweight[c,ci] = sum_{n,p} dy[n,c,p] * skip[n,ci,p],  dbias[c] = sum_{n,p} dy[n,c,p].
+// Persistent workgroups; wave v of a workgroup owns 128/CS of the Ct channels per pass and keeps 128 (+ bias) running sums per lane
+// over all the pixels the workgroup visits; one butterfly reduction and one atomic per sum at the very end.
+template <int CS>
+constexpr int kWChan = 128 / CS;      // 128 running products per lane: 16 / 8 / 4 channels for 8 / 16 / 32 skip channels
+
+template <int CS>
+__global__ void __launch_bounds__(kBlock)
+fpn_merge_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ skip, float* __restrict__ dweight,
+                            float* __restrict__ dbias, MergeDims dm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int HW = dm.H * dm.W;
+    const long long total = (long long)dm.N * HW;
+    constexpr int WC = kWChan<CS>;
+    for (int c0 = wave * WC; c0 < dm.Ct; c0 += (kBlock / kWave) * WC) {
+        float acc[WC][CS], accb[WC];
+#pragma unroll
+        for (int k = 0; k < WC; ++k) {
+            accb[k] = 0.0f;
+#pragma unroll
+            for (int ci = 0; ci < CS; ++ci) acc[k][ci] = 0.0f;
+        }
+        for (long long q = (long long)blockIdx.x * kWave + lane; q < total; q += (long long)gridDim.x * kWave) {
+            const int n = (int)(q / HW), p = (int)(q - (long long)n * HW);
+            float sk[CS];
+#pragma unroll
+            for (int ci = 0; ci < CS; ++ci) sk[ci] = skip[((size_t)n * CS + ci) * HW + p];
+            const float* __restrict__ d = dy + ((size_t)n * dm.Ct + c0) * HW + p;
+#pragma unroll
+            for (int k = 0; k < WC; ++k) {
+                const float g = c0 + k < dm.Ct ? d[(size_t)k * HW] : 0.0f;
+                accb[k] += g;
+#pragma unroll
+                for (int ci = 0; ci < CS; ++ci) acc[k][ci] = fmaf(g, sk[ci], acc[k][ci]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < WC; ++k) {
+            const float sb = group_sum<kWave>(accb[k]);
+            if (lane == 0 && c0 + k < dm.Ct && dbias != nullptr) atomicAdd(dbias + c0 + k, sb);
+#pragma unroll
+            for (int ci = 0; ci < CS; ++ci) {
+                const float sw = group_sum<kWave>(acc[k][ci]);
+                if (lane == 0 && c0 + k < dm.Ct) atomicAdd(dweight + (size_t)(c0 + k) * CS + ci, sw);
+            }
+        }
+    }
+}
+
+// dfeat = transpose of the bilinear x2 upsample applied to dy, as a GATHER (ATen scatters with atomics): a low-resolution
+// pixel (i,j) collects from the <= 6 x 6 high-resolution pixels whose source footprint can contain it, with exactly the
+// forward's weights.
+__global__ void __launch_bounds__(kBlock)
+fpn_upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dfeat, MergeDims dm) {
+    const int plane = blockIdx.y;                       // n * Ct + c
+    const int hw = dm.h * dm.w, HW = dm.H * dm.W;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= hw) return;
+    const int i = p / dm.w, j = p - i * dm.w;
+    const float* __restrict__ d = dy + (size_t)plane * HW;
+    float wy[6], wx[6];
+    const int y0 = 2 * i - 2, x0 = 2 * j - 2;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int yy = y0 + k, xx = x0 + k;
+        wy[k] = 0.0f;
+        wx[k] = 0.0f;
+        if (yy >= 0 && yy < dm.H) {
+            const Lerp l = source_index(yy, dm.sy, dm.h);
+            wy[k] = (l.i0 == i ? l.l0 : 0.0f) + (l.i1 == i ? l.l1 : 0.0f);
+        }
+        if (xx >= 0 && xx < dm.W) {
+            const Lerp l = source_index(xx, dm.sx, dm.w);
+            wx[k] = (l.i0 == j ? l.l0 : 0.0f) + (l.i1 == j ? l.l1 : 0.0f);
+        }
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 6; ++ky) {
+        if (wy[ky] == 0.0f) continue;
+        const float* __restrict__ row = d + (size_t)(y0 + ky) * dm.W;
+        float r = 0.0f;
+#pragma unroll
+        for (int kx = 0; kx < 6; ++kx)
+            if (wx[kx] != 0.0f) r = fmaf(wx[kx], row[x0 + kx], r);
+        acc = fmaf(wy[ky], r, acc);
+    }
+    dfeat[(size_t)plane * hw + p] = acc;
+}
+
+static int check_merge(int N, int Ct, int Cs, int h, int w, MergeDims* dm) {
+    MVSTER_REQUIRE_SHAPE(N > 0 && N <= 65535 && Ct > 0 && Cs > 0 && h > 1 && w > 1);
+    MVSTER_REQUIRE_SHAPE((long long)4 * h * w <= kMaxPlane && (long long)N * Ct <= 65535);
+    if (Ct > kMaxTop || !(Cs == 8 || Cs == 16 || Cs == 32)) return MVSTER_ERR_UNSUPPORTED;
+    *dm = MergeDims{N, Ct, Cs, h, w, 2 * h, 2 * w, (float)(h - 1) / (float)(2 * h - 1), (float)(w - 1) / (float)(2 * w - 1)};
+    return MVSTER_OK;
+}
+
+}  // namespace mvster
+
+#define MVSTER_BY_SKIP(KERNEL, GRID, ...)                                                                \
+    switch (Cs) {                                                                                        \
+        case 8: hipLaunchKernelGGL((KERNEL<8>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;          \
+        case 16: hipLaunchKernelGGL((KERNEL<16>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;        \
+        default: hipLaunchKernelGGL((KERNEL<32>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;        \
+    }
+
+extern "C" int mvster_fpn_merge_fwd(const float* feat, const float* skip, const float* weight, const float* bias, float* y,
+                                    int N, int Ct, int Cs, int h, int w, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(feat); MVSTER_REQUIRE_PTR(skip); MVSTER_REQUIRE_PTR(weight); MVSTER_REQUIRE_PTR(y);
+    MergeDims dm;
+    if (int rc = check_merge(N, Ct, Cs, h, w, &dm)) return rc;
+    const hipStream_t st = as_stream(stream);
+    const dim3 grid(grid_for((long long)dm.H * dm.W, kBlock), N);
+    MVSTER_BY_SKIP(fpn_merge_fwd_kernel, grid, feat, skip, weight, bias, y, dm)
+    return launch_status();
+}
+
+extern "C" int mvster_fpn_merge_bwd(const float* dy, const float* skip, const float* weight, float* dfeat, float* dskip,
+                                    float* dweight, float* dbias, int N, int Ct, int Cs, int h, int w,
+                                    mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(dy); MVSTER_REQUIRE_PTR(skip); MVSTER_REQUIRE_PTR(weight);
+    MVSTER_REQUIRE_PTR(dfeat); MVSTER_REQUIRE_PTR(dskip); MVSTER_REQUIRE_PTR(dweight);
+    MergeDims dm;
+    if (int rc = check_merge(N, Ct, Cs, h, w, &dm)) return rc;
+    const hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Ct * Cs, st) != hipSuccess ||
+        (dbias != nullptr && hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Ct, st) != hipSuccess)) {
+        (void)hipGetLastError();
+        return MVSTER_ERR_LAUNCH;
+    }
+    const dim3 grid(grid_for((long long)dm.H * dm.W, kBlock), N);
+    MVSTER_BY_SKIP(fpn_merge_bwd_skip_kernel, grid, dy, weight, dskip, dm)
+    if (int rc = launch_status()) return rc;
+    // few, long-lived workgroups: every wave ends with 128 (+ bias) atomics onto the same Ct x Cs sums, and 1800 workgroups
+    // doing that took ~1 ms per call whatever the level (same-address contention); two workgroups per CU take < 0.3 ms
+    // (measured: 1800 workgroups 1.0-1.1 ms per call, 512 workgroups 0.36-0.49 ms); and at least 32 pixels per lane so
+    // that the epilogue (128 butterflies + 128 one-lane atomics per wave and pass) does not dominate the small levels
+    const long long want = ((long long)N * dm.H * dm.W + 32 * kWave - 1) / (32 * kWave);
+    const dim3 wgrid((unsigned)(want < 1 ? 1 : want < 512 ? want : 512));
+    MVSTER_BY_SKIP(fpn_merge_bwd_weight_kernel, wgrid, dy, skip, dweight, dbias, dm)
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL(fpn_upsample_bwd_kernel, dim3(grid_for((long long)h * w, kBlock), N * Ct), dim3(kBlock), 0, st, dy,
+                       dfeat, dm);
+    return launch_status();
+}

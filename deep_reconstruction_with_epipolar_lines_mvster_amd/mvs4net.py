@@ -151,6 +151,56 @@ class _ConvBNReLU3d(nn.Module):
         return _batch_norm(self.bn, _conv3d_as_2d(self.conv, x2d, B, D), relu=True)
 
 
+class _TopDownMerge(torch.autograd.Function):
+    """y = bilinear_x2(feat, align_corners=True) + conv1x1(skip; weight, bias), one HIP kernel forward and three streaming
+    passes backward (csrc/fpn_merge.hip) instead of ATen's upsample / atomic upsample backward, a MIOpen 1x1 convolution
+    with its gradient kernels and transposes, a bias reduction and the add -- models/mvs4net_utils.py:490-505."""
+
+    @staticmethod
+    def forward(ctx, feat, skip, weight, bias):
+        N, Ct, h, w = feat.shape
+        Cs = skip.shape[1]
+        y = torch.empty(N, Ct, 2 * h, 2 * w, dtype=torch.float32, device=feat.device)
+        with _on(feat.device):
+            _lib.call("mvster_fpn_merge_fwd", feat.data_ptr(), skip.data_ptr(), weight.data_ptr(),
+                      bias.data_ptr() if bias is not None else None, y.data_ptr(), N, Ct, Cs, h, w, _stream(feat.device))
+        ctx.save_for_backward(skip, weight)
+        ctx.has_bias = bias is not None
+        ctx.lowres = (h, w)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        skip, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, Ct = dy.shape[0], dy.shape[1]
+        Cs = skip.shape[1]
+        h, w = ctx.lowres
+        dfeat = torch.empty(N, Ct, h, w, dtype=torch.float32, device=dy.device)
+        dskip = torch.empty_like(skip)
+        dweight = torch.empty_like(weight)
+        dbias = torch.empty(Ct, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
+        with _on(dy.device):
+            _lib.call("mvster_fpn_merge_bwd", dy.data_ptr(), skip.data_ptr(), weight.data_ptr(), dfeat.data_ptr(),
+                      dskip.data_ptr(), dweight.data_ptr(), dbias.data_ptr() if dbias is not None else None, N, Ct, Cs, h, w,
+                      _stream(dy.device))
+        return dfeat, dskip, dweight, dbias
+
+
+_FUSED_MERGE = True          # FPN4 top-down path through csrc/fpn_merge.hip (HIP fp32 NCHW tensors); False: torch operators
+
+
+def _top_down_merge(feat, skip, lateral):
+    """``F.interpolate(feat, x2, bilinear, align_corners=True) + lateral(skip)`` for a 1x1 ``lateral`` convolution."""
+    fused = (_FUSED_MERGE and feat.is_cuda and feat.dtype == torch.float32 and feat.is_contiguous() and skip.is_contiguous()
+             and feat.shape[1] <= 64 and skip.shape[1] in (8, 16, 32) and feat.shape[2] > 1 and feat.shape[3] > 1
+             and tuple(skip.shape[2:]) == (2 * feat.shape[2], 2 * feat.shape[3]) and lateral.kernel_size == (1, 1))
+    if not fused:
+        return F.interpolate(feat, scale_factor=2, mode="bilinear", align_corners=True) + lateral(skip)
+    return _TopDownMerge.apply(feat, skip, lateral.weight, lateral.bias)
+
+
 def _pyramid_level(cin, cout, downsample):
     first = _ConvBNReLU2d(cin, cout, 5, 2, 2) if downsample else _ConvBNReLU2d(cin, cout, 3, 1, 1)
     rest = [_ConvBNReLU2d(cout, cout, 3, 1, 1) for _ in range(2 if downsample else 1)]
@@ -190,7 +240,7 @@ class FPN4(nn.Module):
         feat = skips[3]
         outs = {"stage1": self.out1(feat)}
         for k, (lateral, head) in enumerate(((self.inner1, self.out2), (self.inner2, self.out3), (self.inner3, self.out4))):
-            feat = F.interpolate(feat, scale_factor=2, mode="bilinear", align_corners=True) + lateral(skips[2 - k])
+            feat = _top_down_merge(feat, skips[2 - k], lateral)
             outs["stage%d" % (k + 2)] = head(feat)
         return outs
 

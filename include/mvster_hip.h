@@ -260,6 +260,19 @@ int mvster_bn_train_bwd_nhwc(const float *dy, const float *x, const float *affin
                              long long M, int C, int relu, mvster_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * F3  top-down merge of the feature pyramid, fused:  y = bilinear_x2(feat, align_corners=True) + conv1x1(skip; weight, bias).
+ * replaces: models/mvs4net_utils.py:490-505 (F.interpolate + innerK 1x1 convolution + add in FPN4.forward) and, in the
+ * backward, ATen's atomic upsample backward, two convolution-gradient kernels with their transposes and a bias reduction.
+ *   feat [N,Ct,h,w]   skip [N,Cs,2h,2w]   weight [Ct,Cs]   bias [Ct] (may be NULL)   y, dy [N,Ct,2h,2w]
+ *   dfeat [N,Ct,h,w]  dskip [N,Cs,2h,2w]  dweight [Ct,Cs]  dbias [Ct] (may be NULL)   -- all overwritten
+ * NCHW planes.  Ct <= 64, Cs in {8,16,32}; otherwise MVSTER_ERR_UNSUPPORTED.
+ */
+int mvster_fpn_merge_fwd(const float *feat, const float *skip, const float *weight, const float *bias, float *y, int N,
+                         int Ct, int Cs, int h, int w, mvster_stream_t stream);
+int mvster_fpn_merge_bwd(const float *dy, const float *skip, const float *weight, float *dfeat, float *dskip,
+                         float *dweight, float *dbias, int N, int Ct, int Cs, int h, int w, mvster_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * F4  geometric consistency of a (reference, source) depth-map pair: project each reference pixel into the source
  * view with its depth, sample the source depth bilinearly (constant border 0), project back, keep the pixel when the
  * round trip lands within `pix_thresh` pixels and `depth_thresh` relative depth.  float64 per-pixel algebra like numpy.

@@ -1,0 +1,70 @@
+"""F3 (GPU): the fused top-down merge of the feature pyramid, y = bilinear_x2(feat, align_corners=True) +
+conv1x1(skip; weight, bias) (csrc/fpn_merge.hip), against the reference's operator sequence
+(models/mvs4net_utils.py:490-505: F.interpolate + nn.Conv2d(1x1) + add) evaluated in float64 on the CPU:
+forward and all four gradients, odd sizes, with and without bias, and the module-level switch inside FPN4."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, what, rel=2e-5):
+    want = want.detach().cpu().double()
+    err = float((got.detach().cpu().double() - want).abs().max())
+    scale = float(want.abs().max())
+    print("    [parity] %-34s max|err| %.3e (max|ref| %.3e)" % (what, err, scale))
+    assert err <= rel * scale + 1e-6, "%s: %.3e" % (what, err)
+
+
+@pytest.mark.parametrize("N,Ct,Cs,h,w,bias", [(2, 64, 8, 13, 17, True), (1, 64, 16, 9, 20, True), (3, 64, 32, 6, 5, True),
+                                              (2, 32, 8, 7, 11, False), (1, 64, 8, 2, 2, True)])
+def test_top_down_merge_matches_torch_operators(N, Ct, Cs, h, w, bias):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N * 100 + Cs + h)
+    feat = torch.randn(N, Ct, h, w, generator=g)
+    skip = torch.randn(N, Cs, 2 * h, 2 * w, generator=g)
+    weight = 0.3 * torch.randn(Ct, Cs, 1, 1, generator=g)
+    b = torch.randn(Ct, generator=g) if bias else None
+    gy = torch.randn(N, Ct, 2 * h, 2 * w, generator=g)
+
+    ref_in = [t.double().requires_grad_(True) if t is not None else None for t in (feat, skip, weight, b)]
+    want = F.interpolate(ref_in[0], scale_factor=2, mode="bilinear", align_corners=True) + F.conv2d(ref_in[1], ref_in[2], ref_in[3])
+    want.backward(gy.double())
+
+    got_in = [t.to(dev).requires_grad_(True) if t is not None else None for t in (feat, skip, weight, b)]
+    got = mvs4net._TopDownMerge.apply(*got_in)
+    got.backward(gy.to(dev))
+    tag = "N%d Ct%d Cs%d %dx%d" % (N, Ct, Cs, h, w)
+    _close(got, want.detach(), tag + " y")
+    for name, a, r in zip(("dfeat", "dskip", "dweight", "dbias"), got_in, ref_in):
+        if a is not None:
+            _close(a.grad, r.grad, tag + " " + name, rel=5e-5)
+
+
+def test_fpn4_uses_the_fused_merge_and_matches_the_operator_path():
+    """FPN4 forward + backward with the fused merge vs the torch operator sequence (same module, switch flipped)."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = mvs4net.FPN4(8).to(dev).train()
+    x = torch.rand(2, 3, 64, 96, device=dev)
+    outs = {}
+    for fused in (True, False):
+        mvs4net._FUSED_MERGE = fused
+        try:
+            net.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            y = net(xin)
+            loss = sum((v * v).mean() for v in y.values())
+            loss.backward()
+            outs[fused] = ({k: v.detach() for k, v in y.items()}, xin.grad, {n: p.grad.clone() for n, p in net.named_parameters()})
+        finally:
+            mvs4net._FUSED_MERGE = True
+    for k in outs[True][0]:
+        _close(outs[True][0][k], outs[False][0][k], "FPN4 " + k, rel=1e-4)
+    _close(outs[True][1], outs[False][1], "FPN4 d/d image", rel=2e-3)
+    for n in outs[True][2]:
+        if "inner" in n:
+            _close(outs[True][2][n], outs[False][2][n], "FPN4 grad " + n, rel=2e-3)
