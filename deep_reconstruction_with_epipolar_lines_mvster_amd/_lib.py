@@ -60,6 +60,7 @@ RESTYPES = {"mvster_cost_volume_bwd_workspace": _ll, "mvster_cost_volume_bwd_rou
 MVSTER_OK = 0
 LAYOUT_NCHW = 0
 LAYOUT_NHWC = 1
+GRAD_PLANAR = 16
 MVSTER_ERR_UNSUPPORTED = 3
 
 _lock = threading.Lock()

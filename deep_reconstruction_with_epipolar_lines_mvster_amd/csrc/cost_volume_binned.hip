@@ -383,6 +383,15 @@ tile_owner_kernel(OwnerArgs a) {
 
     // ---- the tile's only trip to memory: plain 16-byte stores, every pixel of the tile (zeros included) -------------
     float* __restrict__ gsrc = a.gsrcs.p[s] + (size_t)b * HWs * C;
+    if (dm.grad_planar) {                    // [B,C,Hs,Ws] planes: rows of TW pixels per (channel, tile row)
+        for (int e = tid; e < TH * TW * C; e += NT) {
+            const int cellp = e % (TH * TW), chn = e / (TH * TW);
+            const int lx = cellp & (TW - 1), ly = cellp >> LW;
+            const int gx = x0 + lx, gy = y0 + ly;
+            if (gx < dm.Ws && gy < dm.Hs) gsrc[(size_t)chn * HWs + (size_t)gy * dm.Ws + gx] = out[cellp * C + chn];
+        }
+        return;
+    }
     for (int e = tid; e < TH * TW * C / 4; e += NT) {
         const int cellp = (4 * e) / C, chn = (4 * e) % C;
         const int lx = cellp & (TW - 1), ly = cellp >> LW;
@@ -556,6 +565,15 @@ tile_owner_c8_kernel(OwnerArgs a) {
         __syncthreads();
     }
     float* __restrict__ gsrc = a.gsrcs.p[s] + (size_t)b * HWs * C;
+    if (dm.grad_planar) {                    // [B,C,Hs,Ws] planes: rows of TW pixels per (channel, tile row)
+        for (int e = tid; e < TH * TW * C; e += NT) {
+            const int cellp = e % (TH * TW), chn = e / (TH * TW);
+            const int lx = cellp & (TW - 1), ly = cellp >> LW;
+            const int gx = x0 + lx, gy = y0 + ly;
+            if (gx < dm.Ws && gy < dm.Hs) gsrc[(size_t)chn * HWs + (size_t)gy * dm.Ws + gx] = out[cellp * C + chn];
+        }
+        return;
+    }
     for (int e = tid; e < TH * TW * C / 4; e += NT) {
         const int cellp = (4 * e) / C, chn = (4 * e) % C;
         const int lx = cellp & (TW - 1), ly = cellp >> LW;

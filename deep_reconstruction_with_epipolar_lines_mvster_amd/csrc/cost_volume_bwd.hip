@@ -452,6 +452,7 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
         if (bf.cursor != nullptr) write_claimed_items();
     }
     float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C);
+    float* __restrict__ gref_planes = gref + (size_t)b * C * HW + p;            // MVSTER_GRAD_PLANAR: [B,C,H,W]
 #pragma unroll
     for (int c4 = 0; c4 < C4; ++c4) {
         float4 v;
@@ -459,7 +460,16 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
         v.y = group_sum<DL>(dref[4 * c4 + 1]);
         v.z = group_sum<DL>(dref[4 * c4 + 2]);
         v.w = group_sum<DL>(dref[4 * c4 + 3]);
-        if (live && dl == 0) grefp[c4] = v;
+        if (live && dl == 0) {
+            if (dm.grad_planar) {                                                // wave-uniform
+                gref_planes[(size_t)(4 * c4 + 0) * HW] = v.x;
+                gref_planes[(size_t)(4 * c4 + 1) * HW] = v.y;
+                gref_planes[(size_t)(4 * c4 + 2) * HW] = v.z;
+                gref_planes[(size_t)(4 * c4 + 3) * HW] = v.w;
+            } else {
+                grefp[c4] = v;
+            }
+        }
     }
 }
 
@@ -795,6 +805,8 @@ extern "C" int mvster_cost_volume_bwd_ws(const float* gvol, const float* vol, co
     MVSTER_REQUIRE_PTR(gvol); MVSTER_REQUIRE_PTR(vol); MVSTER_REQUIRE_PTR(wsum); MVSTER_REQUIRE_PTR(ref);
     MVSTER_REQUIRE_PTR(srcs); MVSTER_REQUIRE_PTR(pose); MVSTER_REQUIRE_PTR(hypo); MVSTER_REQUIRE_PTR(gref);
     MVSTER_REQUIRE_PTR(gsrcs);
+    const bool grad_planar = (layout & MVSTER_GRAD_PLANAR) != 0;
+    layout &= ~MVSTER_GRAD_PLANAR;
     if (int rc = check_volume(S, B, C, G, D, H, W, Hs, Ws, attn_temp, layout)) return rc;
     SrcPtrs sp{};
     GradPtrs gp{};
@@ -807,6 +819,7 @@ extern "C" int mvster_cost_volume_bwd_ws(const float* gvol, const float* vol, co
     const int route = pick_bwd_route(S, B, C, G, D, H, W, Hs, Ws, layout, workspace != nullptr ? workspace_floats : 0);
     BinnedLayout lay{};
     if (route == MVSTER_BWD_ROUTE_BINNED) binned_layout(S, B, C, G, D, H, W, Hs, Ws, &lay);
+    if (grad_planar && route != MVSTER_BWD_ROUTE_BINNED) return MVSTER_ERR_UNSUPPORTED;   // only the owner kernels write planes
     if (route != MVSTER_BWD_ROUTE_BINNED) {          // the binned route writes every gradient element itself
         for (int s = 0; s < S; ++s) {
             if (hipMemsetAsync(gp.p[s], 0, sizeof(float) * (size_t)B * C * Hs * Ws, st) != hipSuccess) {
@@ -816,6 +829,7 @@ extern "C" int mvster_cost_volume_bwd_ws(const float* gvol, const float* vol, co
         }
     }
     VolumeDims dm = make_dims(H, W, Hs, Ws, S, C, attn_temp);
+    dm.grad_planar = grad_planar ? 1 : 0;
     const int cpg = C / G;
     const bool deferred = route == MVSTER_BWD_ROUTE_BINNED || route == MVSTER_BWD_ROUTE_TILE_SCATTER;
     const bool wide = route == MVSTER_BWD_ROUTE_SPLIT_WINDOW || (route == MVSTER_BWD_ROUTE_PLANAR && pick_pixel_per_lane(B, H * W, C, D));

@@ -20,6 +20,7 @@ struct VolumeDims {
     float temp;     // attn_temp
     float sqrt_c;   // (float)sqrt(C), the reference divides the view weight by math.sqrt(C)
     float inv_temp; // 1 / attn_temp when attn_temp is a power of two (x / temp == x * inv_temp bit for bit), else 0
+    int grad_planar; // backward only: write gref / gsrcs as [B,C,H,W] planes (MVSTER_GRAD_PLANAR) although features are read [B,H,W,C]
 };
 
 // x / attn_temp as the reference computes it; a power-of-two temperature (the scripts' attn_temp 2) divides exactly by
@@ -34,7 +35,7 @@ inline VolumeDims make_dims(int H, int W, int Hs, int Ws, int S, int C, float at
     int e = 0;
     const float m = frexpf(fabsf(attn_temp), &e);
     const bool pow2 = m == 0.5f && e > -100 && e < 100;
-    return VolumeDims{H, W, Hs, Ws, S, 0, attn_temp, (float)sqrt((double)C), pow2 ? 1.0f / attn_temp : 0.0f};
+    return VolumeDims{H, W, Hs, Ws, S, 0, attn_temp, (float)sqrt((double)C), pow2 ? 1.0f / attn_temp : 0.0f, 0};
 }
 
 // (channels per group, groups) pairs instantiated: C in {8,16,32,64} x G in {4,8}

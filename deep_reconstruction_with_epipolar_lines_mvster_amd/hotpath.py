@@ -197,6 +197,7 @@ def to_planar(t):
 # "coefficients" = only the per-hypothesis coefficients (round-1 tiled scatter where it applies), "none" = the plain
 # atomic routes.  Tests and tools switch it to compare the routes; product code leaves it alone.
 BWD_WORKSPACE = "full"
+PLANAR_GRADS = True         # NCHW leaves + binned route: gradients are written as planes by the kernels, no conversion pass
 COUNT_IN_FORWARD = True     # training forward also counts the samples per destination tile for the binned backward
 
 
@@ -259,7 +260,6 @@ class _FusedCostVolume(torch.autograd.Function):
         gvol = gvol.contiguous()
         grads = [torch.empty_like(f) for f in feats]        # same storage layout as the kernel-side features
         pp, keep = _lib.ptr_array(srcs)
-        gp, gkeep = _lib.ptr_array(grads[1:])
         # scratch for the multi-kernel routes (0 words when none applies); torch's caching allocator owns it, the library
         # never allocates
         need = 0
@@ -270,13 +270,20 @@ class _FusedCostVolume(torch.autograd.Function):
         elif BWD_WORKSPACE == "coefficients" and layout == _lib.LAYOUT_NHWC:
             need = B * S * H * W * D * G
         ws = torch.empty(need, dtype=torch.float32, device=ref.device) if need > 0 else None
+        # every leaf NCHW and the owner kernels run: they (and the coefficient kernel) write the gradients as planes directly
+        planar_grads = (PLANAR_GRADS and layout == _lib.LAYOUT_NHWC and not any(was_cl) and
+                        _lib.bwd_route(S, B, C, G, D, H, W, Hs, Ws, layout, need)[1] == "binned")
+        if planar_grads:
+            grads = [torch.empty(f.shape, dtype=torch.float32, device=f.device) for f in feats]
+            layout = layout | _lib.GRAD_PLANAR
+        gp, gkeep = _lib.ptr_array(grads[1:])
         with _on(ref.device):
             _lib.call("mvster_cost_volume_bwd_ws", gvol.data_ptr(), vol.data_ptr(), wsum.data_ptr(), ref.data_ptr(), pp, S,
                       pose.data_ptr(), hypo.data_ptr(), grads[0].data_ptr(), gp, B, C, G, D, H, W, Hs, Ws, attn_temp,
                       layout, ws.data_ptr() if ws is not None else None, need,
                       ctx.bin_counts.data_ptr() if ctx.bin_counts is not None else None, _stream(ref.device))
         del keep, gkeep, ws
-        if layout == _lib.LAYOUT_NHWC:
+        if layout == _lib.LAYOUT_NHWC:                      # (not taken with planar_grads: the flag is part of `layout`)
             todo = [i for i, cl in enumerate(was_cl) if not cl and not grads[i].is_contiguous()]
             if todo:                                        # gradients of the planar leaves, one launch
                 for i, d in zip(todo, _convert_many([grads[i] for i in todo], to_nhwc=False)):

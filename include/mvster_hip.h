@@ -37,6 +37,9 @@ extern "C" {
 
 #define MVSTER_LAYOUT_NCHW 0        /* feature maps are [B,C,H,W] planes (the reference's layout)  */
 #define MVSTER_LAYOUT_NHWC 1        /* feature maps are [B,H,W,C] (torch channels_last storage)    */
+#define MVSTER_GRAD_PLANAR 16       /* flag, OR-ed into `layout` of mvster_cost_volume_bwd_ws with MVSTER_LAYOUT_NHWC: features are
+                                       read channels-last but gref / gsrcs are WRITTEN as [B,C,H,W] planes (for callers whose
+                                       leaves are NCHW: no gradient conversion pass).  Binned route only, else MVSTER_ERR_UNSUPPORTED */
 
 #define MVSTER_MAX_SRC_VIEWS 16     /* source views per call of the fused kernels               */
 #define MVSTER_MAX_DEPTHS 64        /* depth hypotheses per pixel (generic kernels)             */

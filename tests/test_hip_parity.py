@@ -367,24 +367,31 @@ def test_backward_scatter_paths_agree_full_size(dev, stage, coherent):
     hy = hypo.to(dev)
     gvol = torch.randn(1, G, D, H, W, generator=torch.Generator().manual_seed(8)).to(dev)
     grads = {}
+    from deep_reconstruction_with_epipolar_lines_mvster_amd import hotpath
     for route, layout, mode in (("planar", "nchw", "none"), ("binned", "nhwc", "binned"), ("binned_alone", "nhwc", "binned"),
-                                ("coefficients", "nhwc", "coefficients"), ("none", "nhwc", "none")):
+                                ("binned_convert", "nhwc", "binned"), ("coefficients", "nhwc", "coefficients"),
+                                ("none", "nhwc", "none")):
         fin = [f.to(dev).requires_grad_(True) for f in feats]
+        # "binned_convert": the kernels write channels-last gradients and a conversion pass follows (what a caller with
+        # mixed layouts gets); the default for NCHW leaves is planar gradients straight from the kernels
+        hotpath.PLANAR_GRADS = route != "binned_convert"
         # "binned": the forward counts the samples per tile and the coefficient kernel fills the lists;
         # "binned_alone": the backward runs its own count and fill kernels (a forward that did not count)
         with backward_workspace(mode, count_in_forward=route != "binned_alone"):
             vol = mv.fused_cost_volume(fin, pose, hy, G, 2.0, layout=layout)
             vol.backward(gvol)
+        hotpath.PLANAR_GRADS = True
         grads[route] = [f.grad for f in fin]
+        assert all(gr.is_contiguous() for gr in grads[route])
     assert route_for("binned", 2, 1, C, G, D, H, W) == "binned"
     assert route_for("full", 2, 1, C, G, D, H, W) == "binned"                                      # the recommendation
     assert route_for("coefficients", 2, 1, C, G, D, H, W) == ("tile_scatter" if D == 8 else "split_window" if stage == 3 else "dense")
     assert route_for("none", 2, 1, C, G, D, H, W) == ("split_window" if stage == 3 else "dense")
     tag = "stage%d %s" % (stage + 1, "smooth" if coherent else "random")
     for i in range(len(feats)):
-        for route in ("binned", "binned_alone", "coefficients", "none"):
+        for route in ("binned", "binned_alone", "binned_convert", "coefficients", "none"):
             close(grads[route][i], grads["planar"][i], 2e-5, 1e-7,
-                  "%s grad feat%d (%s)" % (tag, i, route if route == "binned_alone" else route_for(route, 2, 1, C, G, D, H, W)))
+                  "%s grad feat%d (%s)" % (tag, i, route if route.startswith("binned_") else route_for(route, 2, 1, C, G, D, H, W)))
 
 
 @pytest.mark.parametrize("mode", ["binned", "binned_alone", "coefficients"])
