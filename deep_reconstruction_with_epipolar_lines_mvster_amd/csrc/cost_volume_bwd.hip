@@ -660,6 +660,153 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
     }
 }
 
+// ------------------------------------------------------------------------------- coefficient kernel, C >= 32: channel-split lanes
+// The DEFER kernel above with a sample shared by HS = C / 16 adjacent lanes of 16 channels each (see
+// cost_volume_fwd_split_kernel): 284 -> ~130 VGPRs at C = 64.  Only the sums over ALL correlation groups (softmax input,
+// dw, godot) cross the lanes of a sample; every lane stores the coefficients of its own groups and the reference gradient
+// of its own channels.  Lanes of a pixel: [d][h], h fastest.  Always deferred (coefficients out, no scatter here).
+template <int C, int G, int D, int HS>
+__global__ void __launch_bounds__(kBlock)
+cost_volume_bwd_coef_split_kernel(const float* __restrict__ gvol, const float* __restrict__ vol,
+                                  const float* __restrict__ wsum, const float* __restrict__ ref, SrcPtrs srcs,
+                                  const float* __restrict__ pose, const float* __restrict__ hypo, float* __restrict__ gref,
+                                  VolumeDims dm, float* __restrict__ dcor_out, BinFill bf) {
+    constexpr int CPG = C / G, CL = C / HS, CL4 = CL / 4, GL = G / HS;
+    static_assert(CL == 16 && CL % CPG == 0 && GL >= 1, "16 channels = whole correlation groups per lane");
+    constexpr int LPP = D * HS;
+    static_assert(LPP <= kWave, "a pixel's lanes live in one wave");
+    constexpr int PXB = kBlock / LPP;
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    if (tile >= dm.ntiles) return;
+    const int b = blockIdx.y;
+    const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
+    const int lane = threadIdx.x & 63;
+    const int h = threadIdx.x % HS, d = (threadIdx.x / HS) % D, pl = threadIdx.x / LPP;
+    const int praw = tile * PXB + pl;
+    const bool live = praw < HW;
+    const int p = live ? praw : HW - 1;
+    const int y = p / dm.W, x = p - y * dm.W;
+    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+    const float inv_tc = 1.0f / (dm.temp * dm.sqrt_c);
+
+    const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C + h * CL);
+    float4 refv[CL4];
+#pragma unroll
+    for (int q4 = 0; q4 < CL4; ++q4) refv[q4] = refp[q4];
+    const float hyp = hypo[((size_t)b * D + d) * HW + p];
+    const float rden = 1.0f / wsum[((size_t)b * D + d) * HW + p];
+    float gd[GL], godot = 0.0f;
+#pragma unroll
+    for (int g = 0; g < GL; ++g) {
+        const size_t at = (((size_t)b * G + h * GL + g) * D + d) * HW + p;
+        gd[g] = live ? gvol[at] * rden : 0.0f;
+        godot = fmaf(gd[g], vol[at], godot);
+    }
+    godot = strided_sum<HS, 1>(godot);
+    float dref[CL];
+#pragma unroll
+    for (int c = 0; c < CL; ++c) dref[c] = 0.0f;
+
+    // second pass of the counting sort, as in the DEFER kernel: claims are consumed one view later
+    int claim_leader[4] = {-1, -1, -1, -1}, claim_rank[4] = {0, 0, 0, 0}, claim_base[4] = {0, 0, 0, 0};
+    auto write_claimed_items = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (__ballot(claim_leader[k] >= 0) == 0) continue;
+            const int base = __shfl(claim_base[k], max(claim_leader[k], 0), kWave);
+            if (claim_leader[k] >= 0) bf.items[base + claim_rank[k]] = p * D + d;
+        }
+    };
+
+    for (int s = 0; s < dm.S; ++s) {
+        const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C + h * CL;
+        const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
+        const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws, half_w, half_h);
+        const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
+        const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
+        const float4* __restrict__ p10 = reinterpret_cast<const float4*>(srcb + (size_t)t.o10 * C);
+        const float4* __restrict__ p11 = reinterpret_cast<const float4*>(srcb + (size_t)t.o11 * C);
+        float warped[CL], cg[GL];
+#pragma unroll
+        for (int g = 0; g < GL; ++g) cg[g] = 0.0f;
+#pragma unroll
+        for (int c4 = 0; c4 < CL4; ++c4) {
+            const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
+            const float4 r = refv[c4];
+            warped[4 * c4 + 0] = fmaf(dq.x, t.w11, fmaf(cq.x, t.w10, fmaf(bq.x, t.w01, a.x * t.w00)));
+            warped[4 * c4 + 1] = fmaf(dq.y, t.w11, fmaf(cq.y, t.w10, fmaf(bq.y, t.w01, a.y * t.w00)));
+            warped[4 * c4 + 2] = fmaf(dq.z, t.w11, fmaf(cq.z, t.w10, fmaf(bq.z, t.w01, a.z * t.w00)));
+            warped[4 * c4 + 3] = fmaf(dq.w, t.w11, fmaf(cq.w, t.w10, fmaf(bq.w, t.w01, a.w * t.w00)));
+            cg[(4 * c4 + 0) / CPG] = fmaf(warped[4 * c4 + 0], r.x, cg[(4 * c4 + 0) / CPG]);
+            cg[(4 * c4 + 1) / CPG] = fmaf(warped[4 * c4 + 1], r.y, cg[(4 * c4 + 1) / CPG]);
+            cg[(4 * c4 + 2) / CPG] = fmaf(warped[4 * c4 + 2], r.z, cg[(4 * c4 + 2) / CPG]);
+            cg[(4 * c4 + 3) / CPG] = fmaf(warped[4 * c4 + 3], r.w, cg[(4 * c4 + 3) / CPG]);
+        }
+        float cor[GL], sg = 0.0f, dwl = 0.0f;
+#pragma unroll
+        for (int g = 0; g < GL; ++g) {
+            cor[g] = cg[g] * (1.0f / CPG);
+            sg = g == 0 ? cor[0] : sg + cor[g];
+            dwl = fmaf(gd[g], cor[g], dwl);
+        }
+        sg = strided_sum<HS, 1>(sg);
+        const float dw = strided_sum<HS, 1>(dwl) - godot;
+        const float a = div_temp(sg, dm);
+        const float m = strided_max<D, HS>(a);
+        const float e = expf(a - m);
+        const float what = e / strided_sum<D, HS>(e);
+        const float sdot = strided_sum<D, HS>(what * dw);
+        const float da = what * (dw - sdot) * inv_tc;
+        const float w = what / dm.sqrt_c;
+        float coef[GL];
+#pragma unroll
+        for (int g = 0; g < GL; ++g) coef[g] = fmaf(gd[g], w, da) * (1.0f / CPG);
+#pragma unroll
+        for (int c = 0; c < CL; ++c) dref[c] = fmaf(coef[c / CPG], warped[c], dref[c]);
+        if (live) {
+            float* __restrict__ out = dcor_out + ((((size_t)b * dm.S + s) * HW + p) * D + d) * G + h * GL;
+            if constexpr (GL == 4) *reinterpret_cast<float4*>(out) = make_float4(coef[0], coef[1], coef[2], coef[3]);
+            else if constexpr (GL == 2) *reinterpret_cast<float2*>(out) = make_float2(coef[0], coef[1]);
+            else out[0] = coef[0];
+        }
+        if (bf.cursor != nullptr) {                                              // wave-uniform
+            write_claimed_items();
+            int id[4];
+            bool emit[4];
+            footprint_tiles(t, bf.bg, id, emit);
+            int* __restrict__ cur = bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int count;
+                wave_group(id[k], live && h == 0 && emit[k], lane, claim_leader[k], claim_rank[k], count);
+                claim_base[k] = lane == claim_leader[k] ? atomicAdd(cur + id[k], count) : 0;
+            }
+        }
+    }
+    if (bf.cursor != nullptr) write_claimed_items();
+    // reference gradient: sum over the D hypothesis lanes of this channel part
+    float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C + h * CL);
+    float* __restrict__ gref_planes = gref + ((size_t)b * C + h * CL) * HW + p;
+#pragma unroll
+    for (int c4 = 0; c4 < CL4; ++c4) {
+        float4 v;
+        v.x = strided_sum<D, HS>(dref[4 * c4 + 0]);
+        v.y = strided_sum<D, HS>(dref[4 * c4 + 1]);
+        v.z = strided_sum<D, HS>(dref[4 * c4 + 2]);
+        v.w = strided_sum<D, HS>(dref[4 * c4 + 3]);
+        if (live && d == 0) {
+            if (dm.grad_planar) {
+                gref_planes[(size_t)(4 * c4 + 0) * HW] = v.x;
+                gref_planes[(size_t)(4 * c4 + 1) * HW] = v.y;
+                gref_planes[(size_t)(4 * c4 + 2) * HW] = v.z;
+                gref_planes[(size_t)(4 * c4 + 3) * HW] = v.w;
+            } else {
+                grefp[c4] = v;
+            }
+        }
+    }
+}
+
 // deferred routes (see DEFER above): coefficients first, then either the tiled LDS-merged atomic scatter of
 // cost_volume_scatter.hip or the binned, atomics-free scatter of cost_volume_binned.hip
 template <int CPG, int G, int D>
@@ -682,8 +829,16 @@ static int launch_bwd_deferred(const float* gvol, const float* vol, const float*
         bf.bg = bin_grid_for(CPG * G, dm.Hs, dm.Ws);
         bf.tiles_per_view = bf.bg.tiles_x * bf.bg.tiles_y;
     }
-    hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, 1, true>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
-                       ref, srcs, pose, hypo, gref, gsrcs, dm, dcor, bf);
+    if constexpr (CPG * G >= 32) {
+        constexpr int HS = CPG * G / 16;
+        dm.ntiles = grid_for((long long)dm.H * dm.W, kBlock / (D * HS));
+        dim3 grid2(((dm.ntiles + 7) / 8) * 8, B);
+        hipLaunchKernelGGL((cost_volume_bwd_coef_split_kernel<CPG * G, G, D, HS>), grid2, dim3(kBlock), 0, st, gvol, vol, wsum,
+                           ref, srcs, pose, hypo, gref, dm, dcor, bf);
+    } else {
+        hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, 1, true>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
+                           ref, srcs, pose, hypo, gref, gsrcs, dm, dcor, bf);
+    }
     if (int rc = launch_status()) return rc;
     if (route == MVSTER_BWD_ROUTE_BINNED)
         return launch_binned_scatter(ref, pose, hypo, gsrcs, B, CPG * G, G, D, dm, workspace, lay, fill_here, st);

@@ -230,12 +230,106 @@ cost_volume_fwd_nhwc_kernel(const float* __restrict__ ref, SrcPtrs srcs, const f
     }
 }
 
+// ------------------------------------------------------------------------------- forward, C >= 32: channel-split lanes
+// With 32 / 64 channels one lane per (pixel, hypothesis) keeps every tap's whole channel vector in flight: 160 / 262
+// VGPRs, three / ONE wave per SIMD, and the kernel waits on its own gathers (0.85 / 0.50 ms at DTU stages 2 / 1 against
+// a ~0.2 / 0.1 ms arithmetic floor).  Here a sample is shared by HS = C / 16 adjacent lanes of 16 channels each (whole
+// correlation groups): a lane's four taps are one 64-byte line each, the lanes of a sample read adjacent lines, and
+// only the sum over all groups (the softmax input) crosses the lanes (xor shuffles).  Lanes of a pixel: [d][h], h fastest.
+template <int C, int G, int D, int HS>
+__global__ void __launch_bounds__(kBlock)
+cost_volume_fwd_split_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float* __restrict__ pose,
+                             const float* __restrict__ hypo, float* __restrict__ vol, float* __restrict__ wsum,
+                             VolumeDims dm, BinCount bc) {
+    constexpr int CPG = C / G, CL = C / HS, CL4 = CL / 4, GL = G / HS;
+    static_assert(CL == 16 && CL % CPG == 0 && GL >= 1, "16 channels = whole correlation groups per lane");
+    constexpr int LPP = D * HS;                    // lanes per pixel
+    static_assert(LPP <= kWave, "a pixel's lanes live in one wave");
+    constexpr int PXB = kBlock / LPP;
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    if (tile >= dm.ntiles) return;
+    const int b = blockIdx.y;
+    const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
+    const int h = threadIdx.x % HS, d = (threadIdx.x / HS) % D, pl = threadIdx.x / LPP;
+    const int praw = tile * PXB + pl;
+    const bool live = praw < HW;
+    const int p = live ? praw : HW - 1;
+    const int y = p / dm.W, x = p - y * dm.W;
+    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+
+    const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C + h * CL);
+    float4 refv[CL4];
+#pragma unroll
+    for (int q4 = 0; q4 < CL4; ++q4) refv[q4] = refp[q4];
+    const float hyp = hypo[((size_t)b * D + d) * HW + p];
+    float den = 1e-8f, num[GL];
+#pragma unroll
+    for (int g = 0; g < GL; ++g) num[g] = 0.0f;
+
+    for (int s = 0; s < dm.S; ++s) {
+        const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C + h * CL;
+        const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
+        const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws, half_w, half_h);
+        if (bc.counters != nullptr)
+            count_sample(bc, bc.counters + ((size_t)b * dm.S + s) * bc.tiles_per_view, t, live && h == 0, threadIdx.x & 63);
+        const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
+        const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
+        const float4* __restrict__ p10 = reinterpret_cast<const float4*>(srcb + (size_t)t.o10 * C);
+        const float4* __restrict__ p11 = reinterpret_cast<const float4*>(srcb + (size_t)t.o11 * C);
+        float cg[GL];
+#pragma unroll
+        for (int g = 0; g < GL; ++g) cg[g] = 0.0f;
+#pragma unroll
+        for (int c4 = 0; c4 < CL4; ++c4) {
+            const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
+            const float4 r = refv[c4];
+            const float w0 = fmaf(dq.x, t.w11, fmaf(cq.x, t.w10, fmaf(bq.x, t.w01, a.x * t.w00)));
+            const float w1 = fmaf(dq.y, t.w11, fmaf(cq.y, t.w10, fmaf(bq.y, t.w01, a.y * t.w00)));
+            const float w2 = fmaf(dq.z, t.w11, fmaf(cq.z, t.w10, fmaf(bq.z, t.w01, a.z * t.w00)));
+            const float w3 = fmaf(dq.w, t.w11, fmaf(cq.w, t.w10, fmaf(bq.w, t.w01, a.w * t.w00)));
+            cg[(4 * c4 + 0) / CPG] = fmaf(w0, r.x, cg[(4 * c4 + 0) / CPG]);
+            cg[(4 * c4 + 1) / CPG] = fmaf(w1, r.y, cg[(4 * c4 + 1) / CPG]);
+            cg[(4 * c4 + 2) / CPG] = fmaf(w2, r.z, cg[(4 * c4 + 2) / CPG]);
+            cg[(4 * c4 + 3) / CPG] = fmaf(w3, r.w, cg[(4 * c4 + 3) / CPG]);
+        }
+        float cor[GL], sg = 0.0f;
+#pragma unroll
+        for (int g = 0; g < GL; ++g) {
+            cor[g] = cg[g] * (1.0f / CPG);
+            sg = g == 0 ? cor[0] : sg + cor[g];
+        }
+        sg = strided_sum<HS, 1>(sg);                                   // all G groups: every lane of the sample
+        const float a = div_temp(sg, dm);
+        const float m = strided_max<D, HS>(a);
+        const float e = expf(a - m);
+        const float sum = strided_sum<D, HS>(e);
+        const float w = (e / sum) / dm.sqrt_c;
+        den += w;
+#pragma unroll
+        for (int g = 0; g < GL; ++g) num[g] += w * cor[g];
+    }
+    if (!live) return;
+#pragma unroll
+    for (int g = 0; g < GL; ++g) vol[(((size_t)b * G + h * GL + g) * D + d) * HW + p] = num[g] / den;
+    if (wsum != nullptr && h == 0) wsum[((size_t)b * D + d) * HW + p] = den;
+}
+
 template <int CPG, int G, int D, int DPL>
 static int launch_fwd(const float* ref, const SrcPtrs& srcs, const float* pose, const float* hypo, float* vol,
                       float* wsum, int B, VolumeDims dm, int layout, const BinCount& bc, hipStream_t st) {
     constexpr int PXB = kBlock / (D / DPL);
     dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
+    if constexpr (CPG * G >= 32 && DPL == 1) {
+        if (layout == MVSTER_LAYOUT_NHWC) {
+            constexpr int HS = CPG * G / 16;
+            dm.ntiles = grid_for((long long)dm.H * dm.W, kBlock / (D * HS));
+            dim3 grid2(((dm.ntiles + 7) / 8) * 8, B);
+            hipLaunchKernelGGL((cost_volume_fwd_split_kernel<CPG * G, G, D, HS>), grid2, dim3(kBlock), 0, st, ref, srcs, pose,
+                               hypo, vol, wsum, dm, bc);
+            return launch_status();
+        }
+    }
     if (layout == MVSTER_LAYOUT_NHWC)
         hipLaunchKernelGGL((cost_volume_fwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, ref, srcs,
                            pose, hypo, vol, wsum, dm, bc);

@@ -159,4 +159,20 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// The same reductions over N lanes that are STRIDE apart (lane bits log2(STRIDE) .. log2(STRIDE*N)-1): used when a pixel's
+// lanes are laid out [hypothesis][channel part] and only one of the two indices is to be reduced.
+template <int N, int STRIDE>
+__device__ __forceinline__ float strided_max(float v) {
+#pragma unroll
+    for (int m = STRIDE; m < N * STRIDE; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));
+    return v;
+}
+
+template <int N, int STRIDE>
+__device__ __forceinline__ float strided_sum(float v) {
+#pragma unroll
+    for (int m = STRIDE; m < N * STRIDE; m <<= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
 }  // namespace mvster

@@ -314,7 +314,7 @@ def test_dtu_stage_forward_backward_vs_oracle(dev, stage):
                                        (64, 8, 16, 7, 9), (16, 8, 4, 12, 18), (8, 8, 8, 12, 18), (64, 4, 4, 8, 10)])
 def test_layout_routes_agree(dev, C, G, D, H, W):
     """The planar (NCHW) and channels-last (NHWC) kernel families run the same arithmetic: forward results are
-    bit-identical, gradients equal up to atomic summation order; channels_last inputs are consumed in place and get
+    bit-identical up to 16 channels (above, only the order of one 4/8-term sum differs), gradients equal up to summation order; channels_last inputs are consumed in place and get
     channels_last gradients; the conversion kernels are exact."""
     g = torch.Generator().manual_seed(C * 100 + D)
     B, S = 2, 3
@@ -340,7 +340,12 @@ def test_layout_routes_agree(dev, C, G, D, H, W):
             assert all(f.grad.is_contiguous(memory_format=torch.channels_last) for f in fin)
         else:
             assert all(f.grad.is_contiguous() for f in fin)
-    assert torch.equal(results["nchw"][0], results["nhwc"][0])
+    if C <= 16:
+        assert torch.equal(results["nchw"][0], results["nhwc"][0])
+    else:
+        # from 32 channels up a sample is shared by C/16 lanes: the sum over the correlation groups (the softmax input)
+        # is a butterfly across them instead of the planar kernel's sequential sum -- last-bit differences only
+        close(results["nhwc"][0], results["nchw"][0], 2e-6, 1e-7, "volume nhwc vs nchw (lane split)")
     assert torch.equal(results["nhwc"][0], results["nhwc_inplace"][0])
     for i in range(S + 1):
         close(results["nhwc"][1][i], results["nchw"][1][i], 1e-5, 1e-7, "grad feat%d nhwc vs nchw" % i)
