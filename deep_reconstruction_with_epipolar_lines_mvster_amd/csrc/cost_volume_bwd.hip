@@ -301,10 +301,9 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
     const int b = blockIdx.y;
     const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
     const int dl = threadIdx.x % DL, pl = threadIdx.x / DL;
-    const int praw = tile * PXB + pl;
-    const bool live = praw < HW;
-    const int p = live ? praw : HW - 1;
-    const int y = p / dm.W, x = p - y * dm.W;
+    const OwnedPixel own = owned_pixel<PXB>(tile, pl, dm.H, dm.W);
+    const bool live = own.live;
+    const int p = own.p, y = own.y, x = own.x;
     const float fx = (float)x, fy = (float)y;
     const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
     const float inv_tc = 1.0f / (dm.temp * dm.sqrt_c);
@@ -815,7 +814,7 @@ static int launch_bwd_deferred(const float* gvol, const float* vol, const float*
                                VolumeDims dm, int route, float* workspace, const BinnedLayout& lay, const int* fwd_counts,
                                hipStream_t st) {
     constexpr int PXB = kBlock / D;
-    dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
+    dm.ntiles = PixelBlocks<PXB>::tiles(dm.H, dm.W);
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
     float* const dcor = workspace + (route == MVSTER_BWD_ROUTE_BINNED ? lay.coef : 0);
     BinFill bf{};
@@ -864,6 +863,8 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
     }
     if (layout == MVSTER_LAYOUT_NHWC) {
         // DPL > 1 is only dispatched for D = 4, C <= 16, which returned into the split kernel above
+        dm.ntiles = PixelBlocks<PXB>::tiles(dm.H, dm.W);
+        grid = dim3(((dm.ntiles + 7) / 8) * 8, B);
         if constexpr (DPL == 1)
             hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol,
                                wsum, ref, srcs, pose, hypo, gref, gsrcs, dm, static_cast<float*>(nullptr), BinFill{});

@@ -137,10 +137,9 @@ cost_volume_fwd_nhwc_kernel(const float* __restrict__ ref, SrcPtrs srcs, const f
     const int b = blockIdx.y;
     const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
     const int dl = threadIdx.x % DL, pl = threadIdx.x / DL;
-    const int praw = tile * PXB + pl;
-    const bool live = praw < HW;
-    const int p = live ? praw : HW - 1;
-    const int y = p / dm.W, x = p - y * dm.W;
+    const OwnedPixel own = owned_pixel<PXB>(tile, pl, dm.H, dm.W);
+    const bool live = own.live;
+    const int p = own.p, y = own.y, x = own.x;
     const float fx = (float)x, fy = (float)y;
     const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
 
@@ -318,7 +317,7 @@ template <int CPG, int G, int D, int DPL>
 static int launch_fwd(const float* ref, const SrcPtrs& srcs, const float* pose, const float* hypo, float* vol,
                       float* wsum, int B, VolumeDims dm, int layout, const BinCount& bc, hipStream_t st) {
     constexpr int PXB = kBlock / (D / DPL);
-    dm.ntiles = grid_for((long long)dm.H * dm.W, PXB);
+    dm.ntiles = layout == MVSTER_LAYOUT_NHWC ? PixelBlocks<PXB>::tiles(dm.H, dm.W) : grid_for((long long)dm.H * dm.W, PXB);
     dim3 grid(((dm.ntiles + 7) / 8) * 8, B);
     if constexpr (CPG * G >= 32 && DPL == 1) {
         if (layout == MVSTER_LAYOUT_NHWC) {
