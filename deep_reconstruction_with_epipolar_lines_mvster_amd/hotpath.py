@@ -291,9 +291,56 @@ class _FusedCostVolume(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
+class _GenericCostVolume(torch.autograd.Function):
+    """The fusion for everything the specialised kernels do not instantiate (csrc/cost_volume_generic.hip): any channel
+    count, ``group_cor=False`` (squared difference), ``attn_fuse_d=False`` (per-pixel maximum of the softmax as the view
+    weight), any D <= 64.  Planar feature maps and gradients."""
+
+    @staticmethod
+    def forward(ctx, pose, hypo, attn_temp, G, group_cor, fuse_d, ref, *srcs):
+        B, C, H, W = ref.shape
+        D = hypo.shape[1]
+        S = len(srcs)
+        Hs, Ws = srcs[0].shape[-2:]
+        feats = tuple(f.contiguous() for f in (ref,) + tuple(srcs))
+        vol = torch.empty(B, G if group_cor else C, D, H, W, dtype=torch.float32, device=ref.device)
+        wsum = torch.empty(B, D, H, W, dtype=torch.float32, device=ref.device)
+        pp, keep = _lib.ptr_array(feats[1:])
+        with _on(ref.device):
+            _lib.call("mvster_cost_volume_generic_fwd", feats[0].data_ptr(), pp, S, pose.data_ptr(), hypo.data_ptr(),
+                      vol.data_ptr(), wsum.data_ptr(), B, C, int(G), D, H, W, Hs, Ws, float(attn_temp), int(bool(group_cor)),
+                      int(bool(fuse_d)), _stream(ref.device))
+        del keep
+        ctx.save_for_backward(pose, hypo, vol, wsum, *feats)
+        ctx.cfg = (float(attn_temp), int(G), bool(group_cor), bool(fuse_d))
+        return vol
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gvol):
+        pose, hypo, vol, wsum = ctx.saved_tensors[:4]
+        feats = ctx.saved_tensors[4:]
+        attn_temp, G, group_cor, fuse_d = ctx.cfg
+        ref, srcs = feats[0], feats[1:]
+        B, C, H, W = ref.shape
+        D = hypo.shape[1]
+        S = len(srcs)
+        Hs, Ws = srcs[0].shape[-2:]
+        gvol = gvol.contiguous()
+        grads = [torch.empty_like(f) for f in feats]
+        pp, keep = _lib.ptr_array(srcs)
+        gp, gkeep = _lib.ptr_array(grads[1:])
+        with _on(ref.device):
+            _lib.call("mvster_cost_volume_generic_bwd", gvol.data_ptr(), vol.data_ptr(), wsum.data_ptr(), ref.data_ptr(), pp, S,
+                      pose.data_ptr(), hypo.data_ptr(), grads[0].data_ptr(), gp, B, C, G, D, H, W, Hs, Ws, attn_temp,
+                      int(group_cor), int(fuse_d), _stream(ref.device))
+        del keep, gkeep
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
 _FUSED_CG = {(8, 4), (16, 4), (32, 4), (64, 4), (8, 8), (16, 8), (32, 8), (64, 8)}
 _FUSED_D = {4, 8, 16}
-_MAX_SRC = 16
+_MAX_SRC = 32
 
 
 def fused_supported(C, G, D, S):
@@ -449,33 +496,6 @@ class stagenet(nn.Module):
         self.attn_temp = attn_temp
         self.debug = debug
 
-    def _composed_volume(self, ref, srcs, pose, depth_hypo, group_cor, G):
-        """Rarely used modes (no group correlation, attn_fuse_d=False, shapes the fused kernel does not
-        instantiate): HIP warp kernel (A1) + device tensor ops, same operator order as
-        models/mvs4net_utils.py:1066-1100."""
-        B, C, H, W = ref.shape
-        D = depth_hypo.shape[1]
-        ref_vol = ref.unsqueeze(2)
-        wsum = 1e-8
-        fused = 0
-        for s, src in enumerate(srcs):
-            warped = _Warp.apply(src, pose[:, s].contiguous(), depth_hypo)
-            if group_cor:
-                cor = (warped.reshape(B, G, C // G, D, H, W) * ref_vol.reshape(B, G, C // G, 1, H, W)).mean(2)
-            else:
-                cor = (ref_vol - warped) ** 2
-            if self.attn_fuse_d:
-                w = torch.softmax(cor.sum(1) / self.attn_temp, 1) / (C ** 0.5)
-                wsum = wsum + w
-                fused = fused + w.unsqueeze(1) * cor
-            else:
-                w = torch.softmax(cor.sum(1), 1).max(1)[0]
-                wsum = wsum + w
-                fused = fused + w.unsqueeze(1).unsqueeze(1) * cor
-        if self.attn_fuse_d:
-            return fused / wsum.unsqueeze(1)
-        return fused / wsum.unsqueeze(1).unsqueeze(1)
-
     def forward(self, features, proj_matrices, depth_hypo, regnet, stage_idx, group_cor=False, group_cor_dim=8,
                 split_itv=1, fn=None):
         if self.vis_ETA:
@@ -500,8 +520,16 @@ class stagenet(nn.Module):
         if group_cor and self.attn_fuse_d and fused_supported(C, int(group_cor_dim), D, S):
             vol = fused_cost_volume([ref] + srcs, pose, hypo, group_cor_dim, self.attn_temp)
         else:
-            vol = self._composed_volume(ref.contiguous(), [t.contiguous() for t in srcs], pose, hypo.detach(),
-                                        group_cor, int(group_cor_dim))
+            # modes / shapes outside the specialised kernels: the generic HIP kernels (planar maps, any C, G, D <= 64)
+            if S > _MAX_SRC or D > 64:
+                raise RuntimeError("at most %d source views and 64 depth hypotheses per stage (got %d, %d)" % (_MAX_SRC, S, D))
+            if group_cor and C % int(group_cor_dim) != 0:
+                raise RuntimeError("group_cor_dim %d does not divide the %d feature channels" % (int(group_cor_dim), C))
+            for t in srcs:
+                if t.shape[:2] != ref.shape[:2] or t.shape[2:] != srcs[0].shape[2:]:
+                    raise RuntimeError("all source feature maps must share [B,C] with the reference and one [Hs,Ws]")
+            vol = _GenericCostVolume.apply(pose, hypo.detach(), float(self.attn_temp), int(group_cor_dim), bool(group_cor),
+                                           bool(self.attn_fuse_d), ref, *srcs)
 
         attn_logits = regnet(vol)                                     # B D H W
         picked = depth_regress(attn_logits, hypo, self.training, self.inverse_depth, split_itv)

@@ -41,7 +41,7 @@ extern "C" {
                                        read channels-last but gref / gsrcs are WRITTEN as [B,C,H,W] planes (for callers whose
                                        leaves are NCHW: no gradient conversion pass).  Binned route only, else MVSTER_ERR_UNSUPPORTED */
 
-#define MVSTER_MAX_SRC_VIEWS 16     /* source views per call of the fused kernels               */
+#define MVSTER_MAX_SRC_VIEWS 32     /* source views per call of the fused kernels               */
 #define MVSTER_MAX_DEPTHS 64        /* depth hypotheses per pixel (generic kernels)             */
 
 typedef void *mvster_stream_t;
@@ -126,6 +126,22 @@ int mvster_cost_volume_fwd_counted(const float *ref, const float *const *srcs, i
                                    const float *hypo, float *vol, float *wsum, int B, int C, int G, int D, int H,
                                    int W, int Hs, int Ws, float attn_temp, int layout, int32_t *bin_counts,
                                    mvster_stream_t stream);
+
+/* A2 / A3 for everything the specialised kernels above do not instantiate: any channel count C, group-wise correlation
+ * with any G dividing C (group_cor != 0) or the per-channel squared difference (ref - warped)^2 of group_cor=False
+ * (group_cor == 0: G is ignored, the volume has C channels), both view-weight modes (attn_fuse_d != 0: softmax over depth
+ * / sqrt(C) per hypothesis; == 0: its maximum over depth per pixel, no temperature), any D <= MVSTER_MAX_DEPTHS.
+ * Planar (NCHW) feature maps and gradients; gsrcs accumulate with fp32 atomics.  Written for coverage, not speed.
+ * replaces: models/mvs4net_utils.py:1066-1100 in the modes no reference script uses, and odd shapes (C = 24, D = 6 ...).
+ *   vol, gvol : [B, G or C, D, H, W]     wsum : [B,D,H,W] (the weight sum; per pixel in the attn_fuse_d == 0 mode, stored per d)
+ */
+int mvster_cost_volume_generic_fwd(const float *ref, const float *const *srcs, int S, const float *pose,
+                                   const float *hypo, float *vol, float *wsum, int B, int C, int G, int D, int H, int W,
+                                   int Hs, int Ws, float attn_temp, int group_cor, int attn_fuse_d, mvster_stream_t stream);
+int mvster_cost_volume_generic_bwd(const float *gvol, const float *vol, const float *wsum, const float *ref,
+                                   const float *const *srcs, int S, const float *pose, const float *hypo, float *gref,
+                                   float *const *gsrcs, int B, int C, int G, int D, int H, int W, int Hs, int Ws,
+                                   float attn_temp, int group_cor, int attn_fuse_d, mvster_stream_t stream);
 
 /* A3  gradient of mvster_cost_volume_fwd w.r.t. every feature map (recompute-based).
  *   gvol : [B,G,D,H,W]   vol, wsum : the forward outputs

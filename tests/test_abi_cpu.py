@@ -55,7 +55,7 @@ def test_argument_checks_run_before_any_launch(lib):
     # C=24 is not instantiated in the fused kernels -> UNSUPPORTED, C % G != 0 -> BAD_SHAPE
     assert lib.mvster_cost_volume_fwd(one, pp, 1, one, one, one, one, 1, 24, 8, 8, 8, 8, 8, 8, 2.0, 1, None) == 3
     assert lib.mvster_cost_volume_fwd(one, pp, 1, one, one, one, one, 1, 30, 8, 8, 8, 8, 8, 8, 2.0, 1, None) == 2
-    assert lib.mvster_cost_volume_fwd(one, pp, 17, one, one, one, one, 1, 32, 8, 8, 8, 8, 8, 8, 2.0, 0, None) == 3
+    assert lib.mvster_cost_volume_fwd(one, pp, 33, one, one, one, one, 1, 32, 8, 8, 8, 8, 8, 8, 2.0, 0, None) == 3
     assert lib.mvster_cost_volume_fwd(one, pp, 1, one, one, one, one, 1, 32, 8, 8, 8, 8, 8, 8, 2.0, 7, None) == 2
     assert lib.mvster_nchw_to_nhwc(one, one, 1, 6, 8, 8, None) == 3
 

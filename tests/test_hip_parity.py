@@ -592,8 +592,8 @@ def test_warp_linearity_and_adjoint_full_size(dev):
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
 
 
-def test_unsupported_shape_uses_composed_hip_route(dev):
-    """C=24 is not instantiated in the fused kernel: stagenet composes the HIP warp kernel with device ops."""
+def test_unsupported_shape_uses_generic_hip_kernels(dev):
+    """C=24, D=6 are not instantiated in the specialised kernels: stagenet runs the generic HIP kernels."""
     g = torch.Generator().manual_seed(11)
     B, C, G, D, H, W, N = 1, 24, 8, 6, 20, 24, 3
     feats = [0.5 * torch.randn(B, C, H, W, generator=g) for _ in range(N)]
@@ -604,7 +604,7 @@ def test_unsupported_shape_uses_composed_hip_route(dev):
     net = mv.stagenet(inverse_depth=True, attn_temp=2.0).eval()
     out = net([f.to(dev) for f in feats], mats.to(dev), hypo.to(dev), lambda v: v.sum(1), 0, group_cor=True,
               group_cor_dim=G, split_itv=1.0)
-    close(out["attn_weight"], want["attn_weight"], 0.0, 1e-4, "composed route attn")
+    close(out["attn_weight"], want["attn_weight"], 0.0, 1e-4, "generic kernels attn")
 
 
 # BASELINE.json configs[0] ("plumbing": 640x512, 3 src views, D = 4,4,4,4) and configs[4] ("high-res": 2048x1536, 9 src
@@ -665,15 +665,57 @@ def test_source_maps_of_another_size_than_the_reference(dev):
     _stage_vs_oracle(dev, feats, mats, hypo, G)
 
 
-@pytest.mark.parametrize("S", [1, 16, 17])
+def test_more_source_views_than_the_kernels_take_raises(dev):
+    feats = [torch.zeros(1, 8, 6, 6, device=dev) for _ in range(34)]
+    mats = synth_views(1, 34, 6, 6, scale=6 / 1600.0).to(dev)
+    with pytest.raises(RuntimeError, match="at most 32 source views"):
+        mv.stagenet(inverse_depth=True, attn_temp=2.0).eval()(feats, mats, torch.full((1, 4, 6, 6), 600.0, device=dev),
+                                                              lambda v: v.sum(1), 0, group_cor=True, group_cor_dim=4)
+
+
+@pytest.mark.parametrize("group_cor,fuse_d,C,G,D", [(False, True, 8, 8, 4), (False, False, 16, 4, 8), (True, False, 32, 8, 8),
+                                                    (True, True, 24, 8, 6), (False, True, 12, 4, 5), (True, False, 8, 4, 3)])
+def test_generic_kernels_all_modes_forward_backward_vs_oracle(dev, group_cor, fuse_d, C, G, D):
+    """The modes no reference script uses -- group_cor=False (squared difference, models/mvs4net_utils.py:1071) and
+    attn_fuse_d=False (:1079-1081) -- and odd shapes run the generic HIP kernels (no torch tensor ops on the path):
+    fused volume and the gradients of every feature map against the CPU oracle's autograd, ragged source size, 2 views."""
+    g = torch.Generator().manual_seed(C * 7 + D)
+    B, S, H, W, Hs, Ws = 2, 2, 11, 14, 12, 13
+    feats = [0.7 * torch.randn(B, C, H, W, generator=g)] + [0.7 * torch.randn(B, C, Hs, Ws, generator=g) for _ in range(S)]
+    mats = synth_views(B, S + 1, H, W, scale=W / 1600.0, yaw_deg=1.0)
+    mats[:, :, 0, :2, 3] *= 0.2
+    base = 1.0 / (520 + 300 * torch.rand(B, 1, H, W, generator=g))
+    hypo = (1.0 / (base + (torch.arange(D).view(1, D, 1, 1) - (D - 1) / 2) * 6e-5)).contiguous()
+    Cc = G if group_cor else C
+    gw = torch.randn(B, Cc, D, H, W, generator=g)
+    cf = [f.clone().requires_grad_(True) for f in feats]
+    want = orc.fuse_source_views(cf, mats, hypo, group_cor, G, 2.0, fuse_d)
+    (want * gw).sum().backward()
+    gf = [f.to(dev).requires_grad_(True) for f in feats]
+    seen = {}
+
+    def regnet(v):
+        seen["vol"] = v
+        return v.sum(1)
+
+    net = mv.stagenet(inverse_depth=True, attn_fuse_d=fuse_d, attn_temp=2.0).train()
+    net(gf, mats.to(dev), hypo.to(dev), regnet, 0, group_cor=group_cor, group_cor_dim=G, split_itv=1.0)
+    tag = "group_cor=%s fuse_d=%s C%d D%d" % (group_cor, fuse_d, C, D)
+    close(seen["vol"], want.detach(), 2e-5, 1e-6, tag + " volume")
+    (seen["vol"] * gw.to(dev)).sum().backward()
+    for i in range(S + 1):
+        close(gf[i].grad, cf[i].grad, 2e-4, 1e-6, tag + " grad feat%d" % i)
+
+
+@pytest.mark.parametrize("S", [1, 16, 17, 32])
 def test_view_count_limits(dev, S):
-    """1 source view, the fused kernels' maximum (16) and one more (17: composed HIP route) all match the oracle."""
+    """1 source view, 16, 17 and the kernels' maximum (32) all match the oracle."""
     g = torch.Generator().manual_seed(30 + S)
     B, C, G, D, H, W = 1, 8, 4, 4, 10, 12
     feats = [0.5 * torch.randn(B, C, H, W, generator=g) for _ in range(S + 1)]
     mats = synth_views(B, S + 1, H, W, scale=W / 1600.0)
-    mats[:, :, 0, 0, 3] *= 0.2        # keep all 17 views inside the tiny map
-    mats[:, :, 0, 1, 3] *= 0.2
+    mats[:, :, 0, 0, 3] *= 0.2 * 16.0 / max(S, 16)        # keep all views inside the tiny map
+    mats[:, :, 0, 1, 3] *= 0.2 * 16.0 / max(S, 16)
     hypo = (600 + 40 * torch.arange(D).view(1, D, 1, 1) + torch.rand(B, 1, H, W, generator=g)).expand(B, D, H, W).contiguous()
     _stage_vs_oracle(dev, feats, mats, hypo, G)
 
@@ -707,7 +749,7 @@ def test_all_views_out_of_bounds_and_nan_inputs(dev):
 def test_randomised_shapes_forward_backward_vs_oracle(dev, seed):
     """Seeded sweep over (C, G, D, S, B, H, W, camera yaw, train/eval, ragged source size): whole stagenet forward and
     the gradients of all feature maps against the oracle.  Covers every fused instantiation family and, for the
-    shapes the fused kernels do not instantiate, the composed HIP route."""
+    shapes the specialised kernels do not instantiate, the generic HIP kernels."""
     import random
     rnd = random.Random(1000 + seed)
     C, G = rnd.choice([(8, 4), (8, 8), (16, 4), (16, 8), (32, 4), (32, 8), (64, 4), (64, 8), (24, 8), (12, 4)])
