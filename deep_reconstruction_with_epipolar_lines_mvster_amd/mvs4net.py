@@ -113,7 +113,8 @@ class _ConvBNReLU2d(nn.Module):
         self.bn = nn.BatchNorm2d(cout, momentum=0.1)
 
     def forward(self, x):
-        return _batch_norm(self.bn, self.conv(x), relu=True)
+        conv = self.conv
+        return _batch_norm(self.bn, _conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), relu=True)
 
 
 def _conv3d_as_2d(conv, x2d, B, D):
@@ -125,14 +126,14 @@ def _conv3d_as_2d(conv, x2d, B, D):
     kd = w.shape[2]
     stride, pad = conv.stride[1:], conv.padding[1:]
     if kd == 1:
-        return F.conv2d(x2d, w[:, :, 0], conv.bias, stride, pad)
+        return _conv2d(x2d, w[:, :, 0], conv.bias, stride, pad)
     assert kd == 3 and conv.stride[0] == 1 and conv.padding[0] == 1
     C, H, W = x2d.shape[1:]
     x5 = x2d.view(B, D, C, H, W)
     pad_slice = x5.new_zeros(B, 1, C, H, W)
     stacked = torch.cat([torch.cat([pad_slice, x5[:, :-1]], 1), x5, torch.cat([x5[:, 1:], pad_slice], 1)], 2)
     w2 = w.permute(0, 2, 1, 3, 4).reshape(w.shape[0], 3 * w.shape[1], w.shape[3], w.shape[4])
-    return F.conv2d(stacked.view(B * D, 3 * C, H, W), w2, conv.bias, stride, pad)
+    return _conv2d(stacked.view(B * D, 3 * C, H, W), w2, conv.bias, stride, pad)
 
 
 class _ConvBNReLU3d(nn.Module):
@@ -149,6 +150,84 @@ class _ConvBNReLU3d(nn.Module):
     def forward_slices(self, x2d, B, D):
         # BatchNorm3d over [B,C,D,H,W] == batch norm over [B*D,C,H,W]: same per-channel statistics, same parameters
         return _batch_norm(self.bn, _conv3d_as_2d(self.conv, x2d, B, D), relu=True)
+
+
+class _DirectConv2d(torch.autograd.Function):
+    """Stride-1 "same" convolution (K = 1 or 3) by the direct HIP kernels of csrc/conv_direct.hip: forward, input gradient
+    (the same kernel on dy with the flipped, transposed weight) and weight / bias gradient (tile partial sums, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, Cin, H, W = x.shape
+        Cout, _, K, _ = weight.shape
+        y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device)
+        wt = weight.detach().permute(1, 2, 3, 0).contiguous()                  # [Cin, K, K, Cout]
+        with _on(x.device):
+            _lib.call("mvster_conv_direct_fwd", x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                      y.data_ptr(), N, Cin, Cout, H, W, K, _stream(x.device))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        Cout, _, K, _ = weight.shape
+        dy = dy.contiguous()
+        dev = x.device
+        dx = dweight = dbias = None
+        lib = _lib.load()
+        with _on(dev):
+            if ctx.needs_input_grad[0]:
+                if Cin <= _DIRECT_MAX_DGRAD_CIN and lib.mvster_conv_direct_supported(Cout, Cin, K):
+                    wt = weight.detach().flip(2, 3).permute(0, 2, 3, 1).contiguous()       # [Cout, K, K, Cin]
+                    dx = torch.empty_like(x)
+                    _lib.call("mvster_conv_direct_fwd", dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, Cout, Cin, H, W, K,
+                              _stream(dev))
+                else:
+                    dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [K // 2, K // 2], [1, 1], False,
+                                                             [0, 0], 1, [True, False, False])[0]
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                need = lib.mvster_conv_direct_wgrad_workspace(N, Cin, Cout, H, W, K)
+                if (Cout <= 8 or Cin * Cout <= _DIRECT_MAX_WGRAD_PRODUCT) and Cout in (1, 8, 16):
+                    ws = torch.empty(need, dtype=torch.float32, device=dev)
+                    dweight = torch.empty_like(weight)
+                    dbias = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+                    _lib.call("mvster_conv_direct_wgrad", x.data_ptr(), dy.data_ptr(), dweight.data_ptr(),
+                              dbias.data_ptr() if dbias is not None else None, ws.data_ptr(), need, N, Cin, Cout, H, W, K,
+                              _stream(dev))
+                else:
+                    _, dweight, dbias = torch.ops.aten.convolution_backward(
+                        dy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [K // 2, K // 2], [1, 1], False, [0, 0], 1,
+                        [False, True, ctx.has_bias])
+        return dx, dweight, dbias
+
+
+_DIRECT_CONV = True          # small-channel stride-1 layers through csrc/conv_direct.hip; False: MIOpen (F.conv2d)
+# Routing policy, from per-operation timings against MIOpen at DTU resolution (tools/probes/conv_probe.py,
+# tools/probes/conv_split_probe.py; ms direct / MIOpen): forward 8->8 0.07/0.24, 4->8 (4 slices) 0.16/0.58, 64->8 0.34/0.75,
+# 8->1 1x1 0.09/0.49, but 64->16 0.26/0.26 and 48->16 0.62/0.60; input gradient 8->8 0.05/0.19, 4->8 0.14/0.67, 8->1
+# 0.04/0.30, but 64->8 0.56/0.35; weight gradient 8->8 0.18/0.28, 64->8 0.84/1.26, 16->8 0.08/0.13, 8->1 0.12/0.43, but
+# 16->16 0.19/0.13, 64->16 0.55/0.31.  MIOpen keeps what it does better: each of the three operations is routed on its own.
+_DIRECT_MAX_COUT = 16                # forward: few output channels ...
+_DIRECT_MAX_PRODUCT = 512            # ... and Cin * Cout small enough to stay memory-bound on the vector units
+_DIRECT_MAX_DGRAD_CIN = 16           # input gradient: Cin accumulators per lane
+_DIRECT_MAX_WGRAD_PRODUCT = 128      # weight gradient: Cout <= 8, or Cin * Cout up to this
+
+
+def _conv2d(x, weight, bias=None, stride=1, padding=0):
+    """F.conv2d, routed to the direct HIP kernels for the layers they are built for."""
+    stride = (stride, stride) if isinstance(stride, int) else tuple(stride)
+    padding = (padding, padding) if isinstance(padding, int) else tuple(padding)
+    K = weight.shape[2]
+    if (_DIRECT_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and weight.shape[2] == weight.shape[3] and K in (1, 3) and stride == (1, 1) and padding == (K // 2, K // 2)
+            and weight.shape[0] <= _DIRECT_MAX_COUT and weight.shape[0] in (1, 3, 4, 8, 16)
+            and weight.shape[0] * weight.shape[1] <= _DIRECT_MAX_PRODUCT):
+        return _DirectConv2d.apply(x, weight, bias)
+    return F.conv2d(x, weight, bias, stride, padding)
 
 
 class _TopDownMerge(torch.autograd.Function):
@@ -238,10 +317,11 @@ class FPN4(nn.Module):
         for level in (self.conv1, self.conv2, self.conv3):
             skips.append(level(skips[-1]))
         feat = skips[3]
-        outs = {"stage1": self.out1(feat)}
+        head_conv = lambda m, t: _conv2d(t, m.weight, m.bias, m.stride, m.padding)
+        outs = {"stage1": head_conv(self.out1, feat)}
         for k, (lateral, head) in enumerate(((self.inner1, self.out2), (self.inner2, self.out3), (self.inner3, self.out4))):
             feat = _top_down_merge(feat, skips[2 - k], lateral)
-            outs["stage%d" % (k + 2)] = head(feat)
+            outs["stage%d" % (k + 2)] = head_conv(head, feat)
         return outs
 
 
@@ -309,7 +389,7 @@ class reg2d(nn.Module):
         y = e2 + self._up(self.conv7, y)
         y = e1 + self._up(self.conv9, y)
         y = e0 + self._up(self.conv11, y)
-        y = F.conv2d(y, self.prob.weight[:, :, 0], self.prob.bias)
+        y = _conv2d(y, self.prob.weight[:, :, 0], self.prob.bias)
         return y.view(B, D, H, W)
 
 
@@ -330,7 +410,8 @@ class mono_depth_decoder(nn.Module):
             coarse = self.convblocks[i - 1](outputs["stage%d" % i]["mono_feat"])
             coarse = F.interpolate(coarse, scale_factor=2, mode=self.interpol)
             fine = outputs["stage%d" % (i + 1)]["mono_feat"]
-            disp = self.sigmoid(self.conv3x3[i - 1](torch.cat([coarse, fine], 1)))
+            last = self.conv3x3[i - 1]
+            disp = self.sigmoid(_conv2d(torch.cat([coarse, fine], 1), last.weight, last.bias, last.stride, last.padding))
             outputs["stage%d" % (i + 1)]["mono_depth"] = (1 / (lo + (hi - lo) * disp)).squeeze(1)
         return outputs
 

@@ -292,6 +292,25 @@ int mvster_fpn_merge_bwd(const float *dy, const float *skip, const float *weight
                          float *dweight, float *dbias, int N, int Ct, int Cs, int h, int w, mvster_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * F2 / F3  direct convolution for the small-channel, full-resolution layers (stride 1, "same" padding, K = 1 or 3; NCHW).
+ * replaces: nn.Conv2d / (1,3,3) nn.Conv3d slices of FPN4 conv0 / out3 / out4, reg2d conv0 / prob, the mono head's c->1
+ * layers (models/mvs4net_utils.py:436-440,452-455,860-870,890,914), which MIOpen runs 4-10x off their memory floor.
+ *   mvster_conv_direct_fwd   : y[n,co] = bias[co] + sum_{ci,tap} wt[ci][tap][co] * x[n,ci, . + tap]
+ *        x [N,CIN,H,W]   wt [CIN,K*K,COUT] (the weight [COUT,CIN,K,K] permuted; for the INPUT gradient pass dy as x and the
+ *        flipped weight permuted to [COUT,K*K,CIN])   bias [COUT] or NULL   y [N,COUT,H,W].  COUT in {1,3,4,8,16,32,64}.
+ *   mvster_conv_direct_wgrad : dweight [COUT,CIN,K,K] (+ dbias [COUT] unless NULL) from x and dy; workspace of
+ *        mvster_conv_direct_wgrad_workspace(...) floats holds per-tile partial sums (no atomics, reproducible).
+ *        COUT*K <= 256 and COUT <= 32, else MVSTER_ERR_UNSUPPORTED.
+ */
+int mvster_conv_direct_supported(int CIN, int COUT, int K);
+int mvster_conv_direct_fwd(const float *x, const float *wt, const float *bias, float *y, int N, int CIN, int COUT, int H,
+                           int W, int K, mvster_stream_t stream);
+long long mvster_conv_direct_wgrad_workspace(int N, int CIN, int COUT, int H, int W, int K);
+int mvster_conv_direct_wgrad(const float *x, const float *dy, float *dweight, float *dbias, float *workspace,
+                             long long workspace_floats, int N, int CIN, int COUT, int H, int W, int K,
+                             mvster_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * F4  geometric consistency of a (reference, source) depth-map pair: project each reference pixel into the source
  * view with its depth, sample the source depth bilinearly (constant border 0), project back, keep the pixel when the
  * round trip lands within `pix_thresh` pixels and `depth_thresh` relative depth.  float64 per-pixel algebra like numpy.
