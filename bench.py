@@ -185,21 +185,24 @@ def source_fingerprint():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(symbol, path=None, fingerprint=None):
-    """HBM bytes per launch of `symbol` from the newest committed PMC summary (tools/pmc_summary.py: separate
-    rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE of this same bench command, gfx950 corrections applied).
-    Returns (bytes, file, entry, reason): bytes is None -- with the reason -- when no summary covers the kernel or when
-    the summary was taken from other kernel sources than the ones in this tree (its "_meta.csrc_sha" differs)."""
+def pmc_traffic(symbols, path=None, fingerprint=None):
+    """HBM bytes per launch of an ABI entry = the sum over its kernels `symbols` (';'-separated, dominant first) from the
+    newest committed PMC summary (tools/pmc_summary.py: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE of
+    this same bench command, gfx950 corrections applied).
+    Returns (bytes, file, entry of the dominant kernel + summed counters, reason): bytes is None -- with the reason -- when
+    no summary covers the dominant kernel or when the summary was taken from other kernel sources than the ones in this
+    tree (its "_meta.csrc_sha" differs)."""
     import glob
+    names = [s for s in symbols.split(";") if s]
     files = [path] if path else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     fingerprint = fingerprint or source_fingerprint()
-    reason = "no PMC summary under profiles/ lists %s" % symbol
+    reason = "no PMC summary under profiles/ lists %s" % names[0]
     for f in reversed(files):
         try:
             doc = json.load(open(f))
         except (OSError, ValueError):
             continue
-        entry = doc.get(symbol)
+        entry = doc.get(names[0])
         if not (entry and "hbm_bytes_per_launch" in entry):
             continue
         rel = os.path.relpath(f, ROOT)
@@ -207,7 +210,12 @@ def pmc_traffic(symbol, path=None, fingerprint=None):
         if have != fingerprint:
             reason = "%s was collected from kernel sources %s, this tree is %s: stale, re-run tools/pmc_pass.sh" % (rel, have, fingerprint)
             continue
-        return entry["hbm_bytes_per_launch"], rel, entry, None
+        found = [doc[n] for n in names if n in doc and "hbm_bytes_per_launch" in doc[n]]
+        total = dict(entry)
+        for key in ("hbm_bytes_per_launch", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "TCC_EA0_ATOMIC_sum_avg"):
+            total[key] = sum(e.get(key, 0.0) for e in found)
+        total["kernels_summed"] = [n for n in names if n in doc]
+        return total["hbm_bytes_per_launch"], rel, total, None
     return None, None, None, reason
 
 
@@ -585,8 +593,10 @@ def main():
                              "achieved_Greq_s": round(pmc["TCC_EA0_ATOMIC_sum_avg"] / (dom["avg_ms"] * 1e-3) / 1e9, 2),
                              "peak_Greq_s": round(1300.0 / 64.0, 2),
                              "frac": round(pmc["TCC_EA0_ATOMIC_sum_avg"] / (dom["avg_ms"] * 1e-3) / 1e9 / (1300.0 / 64.0), 3)},
-                         "kernel": "%s = %s [B%d C%d G%d D%d px%d S%d]" % (dom["entry"], symbol, dom["B"], dom["C"], dom["G"],
-                                                                          dom["D"], dom["HW"], dom["S"]),
+                         "kernel": "%s = %s [B%d C%d G%d D%d px%d S%d]" % (dom["entry"], symbol.replace(";", " + "), dom["B"],
+                                                                          dom["C"], dom["G"], dom["D"], dom["HW"], dom["S"]),
+                         "note": "achieved / avg_launch_ms are the whole entry (all kernels of the route, HIP events around the "
+                                 "C-ABI call); traffic and atomic requests are summed over the same kernels",
                          "avg_launch_ms": round(dom["avg_ms"], 4), "launches_timed": dom["launches"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]},
             "kernels": kernels,

@@ -148,10 +148,11 @@ def bwd_workspace(S, B, C, G, D, H, W, Hs, Ws, layout, route=None):
 
 
 def bwd_route(S, B, C, G, D, H, W, Hs, Ws, layout, workspace_floats):
-    """(route id, route label, dominant kernel symbol as rocprofv3 prints it) the backward entry point picks."""
+    """(route id, route label, kernel symbols as rocprofv3 prints them: dominant first, ';'-separated) of the route the
+    backward entry point picks."""
     lib = load()
     rid = lib.mvster_cost_volume_bwd_route(S, B, C, G, D, H, W, Hs, Ws, layout, workspace_floats)
-    buf = ctypes.create_string_buffer(128)
+    buf = ctypes.create_string_buffer(192)
     lib.mvster_cost_volume_bwd_route_name(rid, C, G, D, buf, len(buf))
     return rid, BWD_ROUTES.get(rid, "route%d" % rid), buf.value.decode()
 

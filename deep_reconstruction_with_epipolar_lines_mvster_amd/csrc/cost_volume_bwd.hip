@@ -915,7 +915,7 @@ extern "C" int mvster_cost_volume_bwd_route(int S, int B, int C, int G, int D, i
 }
 
 extern "C" int mvster_cost_volume_bwd_route_name(int route, int C, int G, int D, char* buf, int cap) {
-    char tmp[96];
+    char tmp[160];
     int n = 0;
     switch (route) {
         case MVSTER_BWD_ROUTE_PLANAR: {
@@ -932,10 +932,16 @@ extern "C" int mvster_cost_volume_bwd_route_name(int route, int C, int G, int D,
         case MVSTER_BWD_ROUTE_TILE_SCATTER:
             n = snprintf(tmp, sizeof tmp, "tile_scatter_kernel<128, 8>");
             break;
-        case MVSTER_BWD_ROUTE_BINNED:
-            if (C == 8) n = snprintf(tmp, sizeof tmp, "tile_owner_c8_kernel<%d, %d>", G, D);
-            else n = snprintf(tmp, sizeof tmp, "tile_owner_kernel<%d, %d, %d>", C, G, D);
+        case MVSTER_BWD_ROUTE_BINNED: {
+            // every kernel of the route that moves real data, dominant first, ';'-separated
+            char owner[48], coef[64];
+            if (C == 8) snprintf(owner, sizeof owner, "tile_owner_c8_kernel<%d, %d>", G, D);
+            else snprintf(owner, sizeof owner, "tile_owner_kernel<%d, %d, %d>", C, G, D);
+            if (C >= 32) snprintf(coef, sizeof coef, "cost_volume_bwd_coef_split_kernel<%d, %d, %d, %d>", C, G, D, C / 16);
+            else snprintf(coef, sizeof coef, "cost_volume_bwd_nhwc_kernel<%d, %d, %d, 1, true>", C, G, D);
+            n = snprintf(tmp, sizeof tmp, "%s;%s", owner, coef);
             break;
+        }
         default:
             tmp[0] = 0;
     }

@@ -183,9 +183,9 @@ int mvster_cost_volume_bwd_ws(const float *gvol, const float *vol, const float *
 
 /* Which kernel family mvster_cost_volume_bwd_ws runs for a shape and workspace size (so that tests and the
  * benchmark can state -- and assert -- the route instead of mirroring the dispatch rules).
- * mvster_cost_volume_bwd_route_name: the route's dominant kernel as rocprofv3 prints it, e.g.
- * "tile_owner_kernel<8, 4, 4>"; writes at most `cap` bytes including the terminator and returns
- * the length it wanted to write (0 for MVSTER_BWD_ROUTE_NONE). */
+ * mvster_cost_volume_bwd_route_name: the route's kernels as rocprofv3 prints them, dominant first, ';'-separated, e.g.
+ * "tile_owner_c8_kernel<4, 4>;cost_volume_bwd_nhwc_kernel<8, 4, 4, 1, true>"; writes at most `cap` bytes including the
+ * terminator and returns the length it wanted to write (0 for MVSTER_BWD_ROUTE_NONE). */
 #define MVSTER_BWD_ROUTE_NONE 0          /* shape not instantiated: the entry point returns MVSTER_ERR_UNSUPPORTED   */
 #define MVSTER_BWD_ROUTE_PLANAR 1        /* NCHW planes, tap-by-tap atomics                                           */
 #define MVSTER_BWD_ROUTE_DENSE 2         /* channels-last, one LDS-transposed dense atomic strip per hypothesis       */

@@ -127,11 +127,15 @@ def test_pmc_traffic_goes_null_when_the_kernel_sources_changed(tmp_path):
     import json
     import bench
     fp = bench.source_fingerprint()
-    doc = {"some_kernel<1>": {"hbm_bytes_per_launch": 123.0, "TCC_EA0_ATOMIC_sum_avg": 5.0}, "_meta": {"csrc_sha": fp}}
+    doc = {"some_kernel<1>": {"hbm_bytes_per_launch": 123.0, "TCC_EA0_ATOMIC_sum_avg": 5.0},
+           "helper_kernel<2>": {"hbm_bytes_per_launch": 77.0, "TCC_EA0_ATOMIC_sum_avg": 1.0}, "_meta": {"csrc_sha": fp}}
     f = tmp_path / "r9_pmc.json"
     f.write_text(json.dumps(doc))
     traffic, src, entry, why = bench.pmc_traffic("some_kernel<1>", path=str(f))
     assert traffic == 123.0 and why is None and entry["TCC_EA0_ATOMIC_sum_avg"] == 5.0
+    # an entry point that launches several kernels: traffic and atomics are summed over them (dominant kernel first)
+    traffic, src, entry, why = bench.pmc_traffic("some_kernel<1>;helper_kernel<2>;absent_kernel", path=str(f))
+    assert traffic == 200.0 and entry["TCC_EA0_ATOMIC_sum_avg"] == 6.0 and entry["kernels_summed"] == ["some_kernel<1>", "helper_kernel<2>"]
     doc["_meta"]["csrc_sha"] = "0" * 16                       # the sources moved on
     f.write_text(json.dumps(doc))
     traffic, src, entry, why = bench.pmc_traffic("some_kernel<1>", path=str(f))
