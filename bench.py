@@ -54,6 +54,14 @@ DTU_STAGES = [
     (1184, 1600, 8, 4, 4, 1.0, 1.0),
 ]
 N_SRC = 4
+# the other BASELINE.json configurations' stage shapes (parity-test cases; `--config` times them for DESIGN.md, the
+# headline line stays the DTU one): (H, W, C, G, D, scale, split_itv), source views, reference views per step
+OTHER_CONFIGS = {
+    "hires": ([(192, 256, 64, 8, 16, 0.125, 0.5), (384, 512, 32, 8, 8, 0.25, 0.5), (768, 1024, 16, 4, 8, 0.5, 0.5),
+               (1536, 2048, 8, 4, 4, 1.0, 1.0)], 9, 1, "High-res 2048x1536, 9 src views, D=(16,8,8,4)"),
+    "plumbing": ([(64, 80, 64, 8, 4, 0.125, 0.5), (128, 160, 32, 8, 4, 0.25, 0.5), (256, 320, 16, 4, 4, 0.5, 0.5),
+                  (512, 640, 8, 4, 4, 1.0, 1.0)], 3, 1, "640x512, 3 src views, D=(4,4,4,4)"),
+}
 DEPTH_RANGE = (425.0, 935.0)
 ATTN_TEMP = 2.0
 DDP_GRAD_ELEMS = 1009119           # parameters of the reference model
@@ -106,15 +114,18 @@ def scene_features(B, C, H, W, n_views, gen, device):
     return feats
 
 
-def make_inputs(B, seed, device, data="noise"):
+def make_inputs(B, seed, device, data="noise", shapes=None, n_src=None):
     g = torch.Generator().manual_seed(seed)
     stages = []
-    for (H, W, C, G, D, scale, itv) in DTU_STAGES:
+    n_src = n_src or N_SRC
+    for (H, W, C, G, D, scale, itv) in (shapes or DTU_STAGES):
         if data == "scene":
-            feats = scene_features(B, C, H, W, N_SRC + 1, g, device)
+            feats = scene_features(B, C, H, W, n_src + 1, g, device)
         else:
-            feats = [torch.randn(B, C, H, W, generator=g).to(device).requires_grad_(True) for _ in range(N_SRC + 1)]
-        mats = synth_views(B, N_SRC + 1, H, W).to(device)
+            feats = [torch.randn(B, C, H, W, generator=g).to(device).requires_grad_(True) for _ in range(n_src + 1)]
+        mats = synth_views(B, n_src + 1, H, W).to(device)
+        if n_src > 4:
+            mats[:, :, 0, :2, 3] *= 4.0 / n_src                      # keep the outer views' baselines inside the DTU rig's span
         lw = torch.randn(B, D, H, W, generator=g).to(device)
         stages.append(dict(feats=feats, mats=mats, lw=lw, H=H, W=W, C=C, G=G, D=D, itv=itv))
     dv = torch.tensor([list(DEPTH_RANGE)] * B).to(device)
@@ -487,6 +498,9 @@ def main():
     ap.add_argument("--data", default="noise", choices=["noise", "scene"],
                     help="noise: N(0,1) features (SURVEY 8d; spatially random depth, worst case for gather/scatter); "
                          "scene: multi-view-consistent textured surface (smooth depth like real data)")
+    ap.add_argument("--config", default="dtu", choices=["dtu"] + sorted(OTHER_CONFIGS),
+                    help="dtu: the headline workload (BASELINE.json metric); hires / plumbing: the other BASELINE configurations' "
+                         "stage shapes, timed for DESIGN.md (their JSON line says so in config.workload; not the headline)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank REHEARSAL on a single GPU: every rank uses cuda:0 and the exchange runs over gloo "
                          "(RCCL refuses two ranks on one device); exercises the N>1 control path, not a measurement")
@@ -518,7 +532,10 @@ def main():
     _lib.load()
 
     B = args.batch
-    stages, dv = make_inputs(B, seed=rank_seed(rank), device=device, data=args.data)
+    other = OTHER_CONFIGS.get(args.config)
+    if other is not None:
+        B = other[2] if args.batch == 4 else args.batch
+    stages, dv = make_inputs(B, seed=rank_seed(rank), device=device, data=args.data, shapes=other and other[0], n_src=other and other[1])
     net = mv.stagenet(inverse_depth=True, mono=True, attn_fuse_d=True, attn_temp=ATTN_TEMP).train()
     exchange = GradientExchange(stages) if distributed else None
     timer = LaunchTimer()
@@ -550,12 +567,13 @@ def main():
                     "avg_ms": round(r["avg_ms"], 4), "launches": r["launches"],
                     "GBps": round(r["algorithmic_bytes"] / (r["avg_ms"] * 1e-3) / 1e9, 1)} for r in rows[:8]]
         symbol = kernel_symbol(dom["entry"], dom["B"], dom["C"], dom["G"], dom["D"], dom["H"], dom["W"], dom["S"])
-        if B == 4 and args.data == "noise":
+        if B == 4 and args.data == "noise" and other is None:
             traffic, traffic_src, pmc, why = pmc_traffic(symbol)
         else:
             traffic, traffic_src, pmc, why = None, None, None, "PMC summaries are collected for --batch 4 --data noise only"
         out = {
-            "metric": "reference-views/sec (fwd+bwd), DTU 1600x1184 N=5 D=(8,8,4,4)",
+            "metric": "reference-views/sec (fwd+bwd), DTU 1600x1184 N=5 D=(8,8,4,4)" if other is None else
+                      "reference-views/sec (fwd+bwd), " + other[3] + " [not the headline metric]",
             "value": whole_job_rate(world, B, args.steps, elapsed),
             "unit": "ref-views/s",
             "n_gpus": world,
@@ -569,9 +587,10 @@ def main():
             "data": "synthetic" if args.data == "noise" else "synthetic (multi-view-consistent scene features)",
             "scope": "hot path only: the regnet callback is a stub (reg2d is illegal at H=1184, SURVEY 8d); the end-to-end "
                      "training step is measured by tools/e2e_bench.py (DESIGN.md section 5)",
-            "config": {"workload": "MVSTER cost-volume hot path fwd+bwd (stub regnet), DTU 1600x1184 stage shapes "
-                                   "148x200/296x400/592x800/1184x1600, 1 ref + 4 src views, D=(8,8,4,4), G=(8,8,4,4), "
-                                   "C=(64,32,16,8), inverse depth, attn_temp 2",
+            "config": {"workload": ("MVSTER cost-volume hot path fwd+bwd (stub regnet), DTU 1600x1184 stage shapes "
+                                    "148x200/296x400/592x800/1184x1600, 1 ref + 4 src views, D=(8,8,4,4), G=(8,8,4,4), "
+                                    "C=(64,32,16,8), inverse depth, attn_temp 2") if other is None else
+                       ("NOT the headline workload -- MVSTER cost-volume hot path fwd+bwd (stub regnet), " + other[3]),
                        "ref_views_per_gpu_per_step": B, "global_batch": B * world,
                        "exchange": "none" if exchange is None else
                        "%d fp32 per step (the reference's DDP gradient volume) as %d async all-reduces over %s issued from "
