@@ -454,17 +454,21 @@ tile_owner_c8_kernel(OwnerArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[k][c] = 0.0f;
 
+    // the item ids of the NEXT chunk are requested while this chunk's data is in flight: one dependent round trip per
+    // chunk instead of two
+    int id_next[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int i = tid + j * NT;
+        id_next[j] = i < n ? a.items[beg + i] : -1;
+    }
     for (int c0 = 0; c0 < n; c0 += CHUNK) {
-        const int m = min(CHUNK, n - c0);
         cnt[tid] = 0;
         __syncthreads();
-        // ---- fetch: ids first, then everything that depends on them, all in flight together ----------------------------
+        // ---- fetch: everything that depends on the ids, all in flight together -----------------------------------------
         int id[KPT];
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const int i = tid + j * NT;
-            id[j] = i < m ? a.items[beg + c0 + i] : -1;
-        }
+        for (int j = 0; j < KPT; ++j) id[j] = id_next[j];
         float hyp[KPT], cf[KPT][G];
         float4 r0[KPT], r1[KPT];
 #pragma unroll
@@ -482,6 +486,11 @@ tile_owner_c8_kernel(OwnerArgs a) {
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(ref + (size_t)p * C);
             r0[j] = rp[0];
             r1[j] = rp[1];
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int i = c0 + CHUNK + tid + j * NT;
+            id_next[j] = i < n ? a.items[beg + i] : -1;
         }
         // ---- project, count per owner ----------------------------------------------------------------------------------
         StagedRec rec[KPT];

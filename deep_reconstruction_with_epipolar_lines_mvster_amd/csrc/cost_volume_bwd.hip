@@ -438,8 +438,13 @@ cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restr
                 bool emit[4];
                 footprint_tiles(taps[0], bf.bg, id, emit);
                 int* __restrict__ cur = bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view;
+                const bool straddles = __ballot(live && (emit[1] | emit[2] | emit[3])) != 0;     // wave-uniform
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+                    if (k > 0 && !straddles) {
+                        claim_leader[k] = -1;
+                        continue;
+                    }
                     int count;
                     wave_group(id[k], live && emit[k], lane, claim_leader[k], claim_rank[k], count);
                     claim_base[k] = lane == claim_leader[k] ? atomicAdd(cur + id[k], count) : 0;
@@ -774,8 +779,13 @@ cost_volume_bwd_coef_split_kernel(const float* __restrict__ gvol, const float* _
             bool emit[4];
             footprint_tiles(t, bf.bg, id, emit);
             int* __restrict__ cur = bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view;
+            const bool straddles = __ballot(live && h == 0 && (emit[1] | emit[2] | emit[3])) != 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                if (k > 0 && !straddles) {
+                    claim_leader[k] = -1;
+                    continue;
+                }
                 int count;
                 wave_group(id[k], live && h == 0 && emit[k], lane, claim_leader[k], claim_rank[k], count);
                 claim_base[k] = lane == claim_leader[k] ? atomicAdd(cur + id[k], count) : 0;

@@ -248,8 +248,11 @@ __device__ __forceinline__ void count_sample(const BinCount& bc, int* __restrict
     int id[4];
     bool emit[4];
     footprint_tiles(t, bc.bg, id, emit);
+    // taps 1-3 open a new tile only when the footprint straddles a tile edge: one ballot skips their three rounds
+    const bool straddles = __ballot(live && (emit[1] | emit[2] | emit[3])) != 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        if (k > 0 && !straddles) break;
         int leader, rank, count;
         wave_group(id[k], live && emit[k], lane, leader, rank, count);
         if (lane == leader) atomicAdd(view_counters + id[k], count);
