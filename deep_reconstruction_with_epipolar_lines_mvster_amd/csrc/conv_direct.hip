@@ -27,41 +27,60 @@ struct ConvDims {
     int N, CIN, H, W;
 };
 
-template <int COUT, int K>
+// PX horizontally adjacent output pixels per lane.  PX = 2 (COUT >= 16): the K x (K+1) input window is loaded once and the two
+// accumulator sets pair up into packed FMAs -- the many-accumulator cases (the 8->64 input gradient of the 64->8 layer,
+// 64->16, 48->16) are bound by FMA issue: 0.57 -> 0.37, 0.26 -> 0.21, 0.62 -> 0.43 ms.  PX = 1 (COUT <= 8): those layers are
+// bound by memory and want the lanes (64->8 forward 0.34 ms with one pixel per lane, 0.46 with two).
+template <int COUT, int K, int PX>
 __global__ void __launch_bounds__(kBlock)
 conv_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
                        float* __restrict__ y, ConvDims dm) {
-    constexpr int P = K / 2, KK = K * K;
+    constexpr int P = K / 2, KK = K * K, WIN = K + PX - 1;
     const int n = blockIdx.y, HW = dm.H * dm.W;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= HW) return;
-    const int yy = p / dm.W, xx = p - yy * dm.W;
-    float acc[COUT];
+    const int per_row = (dm.W + PX - 1) / PX;
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= dm.H * per_row) return;
+    const int yy = q / per_row, xx = PX * (q - yy * per_row);
+    float acc[COUT][PX];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = bias != nullptr ? bias[co] : 0.0f;
-    // tap offsets and validity do not depend on the channel
-    int off[KK];
-    bool ok[KK];
+    for (int co = 0; co < COUT; ++co) {
+        const float b0 = bias != nullptr ? bias[co] : 0.0f;
 #pragma unroll
-    for (int t = 0; t < KK; ++t) {
-        const int iy = yy + t / K - P, ix = xx + t % K - P;
+        for (int j = 0; j < PX; ++j) acc[co][j] = b0;
+    }
+    // window offsets and validity do not depend on the channel: rows yy-P..yy+P, columns xx-P..xx+P+PX-1
+    int off[K * WIN];
+    bool ok[K * WIN];
+#pragma unroll
+    for (int t = 0; t < K * WIN; ++t) {
+        const int iy = yy + t / WIN - P, ix = xx + t % WIN - P;
         ok[t] = iy >= 0 && iy < dm.H && ix >= 0 && ix < dm.W;
-        off[t] = ok[t] ? iy * dm.W + ix : p;
+        off[t] = ok[t] ? iy * dm.W + ix : yy * dm.W + xx;
     }
     const float* __restrict__ xb = x + (size_t)n * dm.CIN * HW;
     for (int ci = 0; ci < dm.CIN; ++ci) {
         const float* __restrict__ plane = xb + (size_t)ci * HW;
         const float* __restrict__ w = wt + (size_t)ci * KK * COUT;                 // wave-uniform: scalar loads
+        float v[K * WIN];
 #pragma unroll
-        for (int t = 0; t < KK; ++t) {
-            const float v = ok[t] ? plane[off[t]] : 0.0f;
+        for (int t = 0; t < K * WIN; ++t) v[t] = ok[t] ? plane[off[t]] : 0.0f;
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v, w[t * COUT + co], acc[co]);
-        }
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const float wv = w[(ky * K + kx) * COUT + co];
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) acc[co][j] = fmaf(v[ky * WIN + kx + j], wv, acc[co][j]);
+                }
     }
-    float* __restrict__ yb = y + (size_t)n * COUT * HW + p;
+    float* __restrict__ yb = y + (size_t)n * COUT * HW + (size_t)yy * dm.W + xx;
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) yb[(size_t)co * HW] = acc[co];
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int j = 0; j < PX; ++j)
+            if (xx + j < dm.W) yb[(size_t)co * HW + j] = acc[co][j];
 }
 
 // ---- weight gradient ------------------------------------------------------------------------------------------------
@@ -251,11 +270,14 @@ extern "C" int mvster_conv_direct_supported(int CIN, int COUT, int K) {
     return (K == 1 || K == 3) && CIN > 0 && conv_cout_supported(COUT) ? 1 : 0;
 }
 
-#define MVSTER_CONV_CASE(CO)                                                                                         \
-    case CO:                                                                                                         \
-        if (K == 3) hipLaunchKernelGGL((conv_direct_fwd_kernel<CO, 3>), grid, dim3(kBlock), 0, st, x, wt, bias, y, dm); \
-        else hipLaunchKernelGGL((conv_direct_fwd_kernel<CO, 1>), grid, dim3(kBlock), 0, st, x, wt, bias, y, dm);      \
-        break;
+#define MVSTER_CONV_CASE(CO)                                                                                                \
+    case CO: {                                                                                                              \
+        constexpr int PX = CO >= 16 ? 2 : 1;                                                                                \
+        const dim3 grid(grid_for((long long)H * ((W + PX - 1) / PX), kBlock), N);                                           \
+        if (K == 3) hipLaunchKernelGGL((conv_direct_fwd_kernel<CO, 3, PX>), grid, dim3(kBlock), 0, st, x, wt, bias, y, dm); \
+        else hipLaunchKernelGGL((conv_direct_fwd_kernel<CO, 1, PX>), grid, dim3(kBlock), 0, st, x, wt, bias, y, dm);      \
+        break;                                                                                                              \
+    }
 
 extern "C" int mvster_conv_direct_fwd(const float* x, const float* wt, const float* bias, float* y, int N, int CIN, int COUT,
                                       int H, int W, int K, mvster_stream_t stream) {
@@ -264,7 +286,6 @@ extern "C" int mvster_conv_direct_fwd(const float* x, const float* wt, const flo
     MVSTER_REQUIRE_SHAPE(N > 0 && N <= 65535 && CIN > 0 && COUT > 0 && H > 0 && W > 0 && (long long)H * W <= kMaxPlane);
     if (!mvster_conv_direct_supported(CIN, COUT, K)) return MVSTER_ERR_UNSUPPORTED;
     const ConvDims dm{N, CIN, H, W};
-    const dim3 grid(grid_for((long long)H * W, kBlock), N);
     const hipStream_t st = as_stream(stream);
     switch (COUT) {
         MVSTER_CONV_CASE(1) MVSTER_CONV_CASE(3) MVSTER_CONV_CASE(4) MVSTER_CONV_CASE(8)

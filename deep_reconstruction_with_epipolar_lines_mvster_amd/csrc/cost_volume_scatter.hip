@@ -42,13 +42,14 @@ struct ScatterArgs {
     int C, G, D, tiles_x;
 };
 
-// Orders the LDS accesses of one wave across its lanes.  The LDS executes the instructions of a wave in issue order, so
-// a later read by any lane sees an earlier write by any other lane of the same wave: only the COMPILER has to keep the
-// order (no s_waitcnt, which a wavefront-scope fence would add after every step).
+// Orders the LDS accesses of one wave across its lanes: a wavefront-scope release / acquire pair around a wave barrier
+// (s_waitcnt lgkmcnt(0) + barrier).  Round 1 relied on the LDS returning one wave's operations in issue order and used a
+// compiler barrier only; this kernel is a fallback route now (the binned route is the default), so it pays the few
+// per cent for the documented ordering instead.
 __device__ __forceinline__ void wave_sync() {
-    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // The four taps of one hypothesis are the source pixels (ix,iy) (ix+1,iy) (ix,iy+1) (ix+1,iy+1).  With the entry index

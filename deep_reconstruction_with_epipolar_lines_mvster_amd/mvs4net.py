@@ -212,7 +212,7 @@ _DIRECT_CONV = True          # small-channel stride-1 layers through csrc/conv_d
 # 0.04/0.30, but 64->8 0.56/0.35; weight gradient 8->8 0.18/0.28, 64->8 0.84/1.26, 16->8 0.08/0.13, 8->1 0.12/0.43, but
 # 16->16 0.19/0.13, 64->16 0.55/0.31.  MIOpen keeps what it does better: each of the three operations is routed on its own.
 _DIRECT_MAX_COUT = 16                # forward: few output channels ...
-_DIRECT_MAX_PRODUCT = 512            # ... and Cin * Cout small enough to stay memory-bound on the vector units
+_DIRECT_MAX_PRODUCT = 1024           # ... and Cin * Cout up to 64 x 16 (two pixels per lane from 16 accumulators up)
 _DIRECT_MAX_DGRAD_CIN = 16           # input gradient: Cin accumulators per lane
 _DIRECT_MAX_WGRAD_PRODUCT = 128      # weight gradient: Cout <= 8, or Cin * Cout up to this
 

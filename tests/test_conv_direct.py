@@ -66,10 +66,11 @@ def test_routing_policy():
         mvs4net._conv2d(x, torch.randn(1, 8, 1, 1, device=dev), torch.zeros(1, device=dev), 1, 0)   # direct
         x64 = torch.randn(1, 64, 16, 16, device=dev)
         mvs4net._conv2d(x64, torch.randn(8, 64, 3, 3, device=dev), None, 1, 1)         # 64 -> 8: direct (forward)
-        mvs4net._conv2d(x64, torch.randn(16, 64, 3, 3, device=dev), None, 1, 1)        # 64 -> 16: MIOpen is as fast
+        mvs4net._conv2d(x64, torch.randn(16, 64, 3, 3, device=dev), None, 1, 1)        # 64 -> 16: direct (two pixels per lane)
+        mvs4net._conv2d(torch.randn(1, 96, 16, 16, device=dev), torch.randn(16, 96, 3, 3, device=dev), None, 1, 1)   # Cin*Cout > 1024: MIOpen
     finally:
         mvs4net._DirectConv2d.apply = real
-    assert [tuple(c) for c in calls] == [(8, 8, 3, 3), (1, 8, 1, 1), (8, 64, 3, 3)]
+    assert [tuple(c) for c in calls] == [(8, 8, 3, 3), (1, 8, 1, 1), (8, 64, 3, 3), (16, 64, 3, 3)]
 
 
 def test_mixed_backward_routing_matches_torch():
