@@ -84,9 +84,12 @@ conv_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt
 }
 
 // ---- weight gradient ------------------------------------------------------------------------------------------------
-constexpr int kWgTileW = 64, kWgTileH = 16;          // pixels of a workgroup's tile
+#ifndef MVSTER_WG_TILE_H
+#define MVSTER_WG_TILE_H 16
+#endif
+constexpr int kWgTileW = 64, kWgTileH = MVSTER_WG_TILE_H;   // pixels of a workgroup's tile (64 x 8 tiles: no faster, and the scratch no longer fits the input tiles for COUT = 16)
 constexpr int kDyRow = kWgTileW + 1;                 // LDS strides chosen so that the lanes of a wave -- same column, different
-constexpr int kDyChan = kWgTileH * kDyRow + 56;      // (channel, row) -- fall on different banks: row stride = 1, channel stride = 8 (mod 64)
+constexpr int kDyChan = kWgTileH * kDyRow + (8 - (kWgTileH * kDyRow) % 64 + 64) % 64;   // (channel, row) -- fall on different banks: row stride = 1, channel stride = 8 (mod 64)
 
 struct WgradDims {
     int N, CIN, H, W, tiles_x, tiles_y;
