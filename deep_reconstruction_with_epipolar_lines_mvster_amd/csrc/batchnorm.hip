@@ -33,13 +33,17 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* __restr
     }
 }
 
-// sums[c] = { sum(x - K_c), sum((x - K_c)^2) } with K_c = x[0, c, 0]: shifting by a sample of the channel keeps
+// Statistic groups: the N samples are `groups` runs of Ng consecutive samples, each normalised with its own batch
+// statistics (the reference pushes every view through the pyramid on its own, models/MVS4Net.py:88-93: one launch over
+// all views here, same numbers).  Per-(group, channel) arrays are indexed gc = group * C + c.
+// sums[gc] = { sum(x - K), sum((x - K)^2) } with K = the group's first element of the channel: shifting by a sample keeps
 // E[(x-K)^2] - E[x-K]^2 free of the cancellation the raw moments suffer when |mean| >> std.
 __global__ void __launch_bounds__(kBlock)
-bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int C, int HW) {
+bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int C, int HW, int Ng) {
     __shared__ double scratch[8];
     const int c = blockIdx.y, n = blockIdx.z;
-    const float shift = x[(size_t)c * HW];
+    const int g = n / Ng, gc = g * C + c;
+    const float shift = x[((size_t)g * Ng * C + c) * HW];
     const float* __restrict__ plane = x + ((size_t)n * C + c) * HW;
     const int base = blockIdx.x * (kBlock * kBnVec * kBnIters);
     float s1 = 0.0f, s2 = 0.0f;
@@ -64,8 +68,8 @@ bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, int C, i
     double d1 = s1, d2 = s2;
     block_sum2(d1, d2, scratch);
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[2 * c], d1);
-        atomicAdd(&sums[2 * c + 1], d2);
+        atomicAdd(&sums[2 * gc], d1);
+        atomicAdd(&sums[2 * gc + 1], d2);
     }
 }
 
@@ -75,34 +79,38 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const double* __
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ affine, int C, int HW, double count, float momentum, float eps) {
+                                   float* __restrict__ affine, int C, int HW, int Ng, int groups, double count,
+                                   float momentum, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double shift = (double)x[(size_t)c * HW];
-    const double m1 = sums[2 * c] / count, m2 = sums[2 * c + 1] / count;
-    const double mean = shift + m1;
-    double var = m2 - m1 * m1;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    save_mean[c] = (float)mean;
-    save_invstd[c] = invstd;
-    if (running_mean != nullptr) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-    }
     const float g = gamma != nullptr ? gamma[c] : 1.0f, b = beta != nullptr ? beta[c] : 0.0f;
-    const float a = g * invstd;
-    affine[2 * c] = a;           // y = (x - mean) * a + beta: subtracting the mean first keeps fp32 exact-ish for |mean| >> std
-    affine[2 * c + 1] = b;
+    for (int grp = 0; grp < groups; ++grp) {                      // in order: the running statistics see the groups one by one
+        const int gc = grp * C + c;
+        const double shift = (double)x[((size_t)grp * Ng * C + c) * HW];
+        const double m1 = sums[2 * gc] / count, m2 = sums[2 * gc + 1] / count;
+        const double mean = shift + m1;
+        double var = m2 - m1 * m1;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        save_mean[gc] = (float)mean;
+        save_invstd[gc] = invstd;
+        if (running_mean != nullptr) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+        affine[2 * gc] = g * invstd;   // y = (x - mean) * a + beta: subtracting the mean first keeps fp32 exact-ish for |mean| >> std
+        affine[2 * gc + 1] = b;
+    }
 }
 
 template <bool RELU>
 __global__ void __launch_bounds__(kBlock)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ affine, const float* __restrict__ save_mean,
-                float* __restrict__ y, int C, int HW) {
+                float* __restrict__ y, int C, int HW, int Ng) {
     const int c = blockIdx.y, n = blockIdx.z;
-    const float a = affine[2 * c], b = affine[2 * c + 1], mean = save_mean[c];
+    const int gc = (n / Ng) * C + c;
+    const float a = affine[2 * gc], b = affine[2 * gc + 1], mean = save_mean[gc];
     const size_t off = ((size_t)n * C + c) * HW;
     const int base = blockIdx.x * (kBlock * kBnVec * kBnIters);
     const bool vec_ok = (HW % kBnVec) == 0;
@@ -124,15 +132,16 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ affine, c
     }
 }
 
-// sums[c] = { sum(dy'), sum(dy' * xhat) }
+// sums[gc] = { sum(dy'), sum(dy' * xhat) }
 template <bool RELU>
 __global__ void __launch_bounds__(kBlock)
 bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ affine,
                     const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-                    double* __restrict__ sums, int C, int HW) {
+                    double* __restrict__ sums, int C, int HW, int Ng) {
     __shared__ double scratch[8];
     const int c = blockIdx.y, n = blockIdx.z;
-    const float a = affine[2 * c], b = affine[2 * c + 1], mean = save_mean[c], invstd = save_invstd[c];
+    const int gc = (n / Ng) * C + c;
+    const float a = affine[2 * gc], b = affine[2 * gc + 1], mean = save_mean[gc], invstd = save_invstd[gc];
     const size_t off = ((size_t)n * C + c) * HW;
     const int base = blockIdx.x * (kBlock * kBnVec * kBnIters);
     float s1 = 0.0f, s2 = 0.0f;
@@ -157,8 +166,8 @@ bn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x, c
     double d1 = s1, d2 = s2;
     block_sum2(d1, d2, scratch);
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[2 * c], d1);
-        atomicAdd(&sums[2 * c + 1], d2);
+        atomicAdd(&sums[2 * gc], d1);
+        atomicAdd(&sums[2 * gc + 1], d2);
     }
 }
 
@@ -167,13 +176,19 @@ __global__ void __launch_bounds__(kBlock)
 bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ affine,
                     const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                     const double* __restrict__ sums, float* __restrict__ dx, float* __restrict__ dgamma,
-                    float* __restrict__ dbeta, int C, int HW, double count) {
+                    float* __restrict__ dbeta, int C, int HW, int Ng, int groups, double count) {
     const int c = blockIdx.y, n = blockIdx.z;
-    const float a = affine[2 * c], b = affine[2 * c + 1], mean = save_mean[c], invstd = save_invstd[c];
-    const float mean_dy = (float)(sums[2 * c] / count), mean_dyx = (float)(sums[2 * c + 1] / count);
-    if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
-        if (dbeta != nullptr) dbeta[c] = (float)sums[2 * c];
-        if (dgamma != nullptr) dgamma[c] = (float)sums[2 * c + 1];
+    const int gc = (n / Ng) * C + c;
+    const float a = affine[2 * gc], b = affine[2 * gc + 1], mean = save_mean[gc], invstd = save_invstd[gc];
+    const float mean_dy = (float)(sums[2 * gc] / count), mean_dyx = (float)(sums[2 * gc + 1] / count);
+    if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {          // gamma and beta are shared by the groups: their gradients add
+        double db = 0.0, dg = 0.0;
+        for (int grp = 0; grp < groups; ++grp) {
+            db += sums[2 * (grp * C + c)];
+            dg += sums[2 * (grp * C + c) + 1];
+        }
+        if (dbeta != nullptr) dbeta[c] = (float)db;
+        if (dgamma != nullptr) dgamma[c] = (float)dg;
     }
     const size_t off = ((size_t)n * C + c) * HW;
     const int base = blockIdx.x * (kBlock * kBnVec * kBnIters);
@@ -368,45 +383,63 @@ static int check_bn(int N, int C, int HW) {
 
 }  // namespace mvster
 
-extern "C" int mvster_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
-                                   float* save_invstd, float* running_mean, float* running_var, double* sums,
-                                   float* affine, int N, int C, int HW, float momentum, float eps, int relu,
-                                   mvster_stream_t stream) {
+extern "C" int mvster_bn_train_fwd_grouped(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                                           float* save_invstd, float* running_mean, float* running_var, double* sums,
+                                           float* affine, int N, int C, int HW, int groups, float momentum, float eps,
+                                           int relu, mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(save_mean); MVSTER_REQUIRE_PTR(save_invstd);
     MVSTER_REQUIRE_PTR(sums); MVSTER_REQUIRE_PTR(affine);
     MVSTER_REQUIRE_SHAPE((running_mean == nullptr) == (running_var == nullptr));
     if (int rc = check_bn(N, C, HW)) return rc;
+    MVSTER_REQUIRE_SHAPE(groups > 0 && N % groups == 0);
+    const int Ng = N / groups;
     const hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { (void)hipGetLastError(); return MVSTER_ERR_LAUNCH; }
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * groups, st) != hipSuccess) { (void)hipGetLastError(); return MVSTER_ERR_LAUNCH; }
     dim3 grid(grid_for(HW, kBlock * kBnVec * kBnIters), C, N);
-    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBlock), 0, st, x, sums, C, HW);
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBlock), 0, st, x, sums, C, HW, Ng);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid_for(C, 64)), dim3(64), 0, st, x, sums, gamma, beta, save_mean,
-                       save_invstd, running_mean, running_var, affine, C, HW, (double)N * HW, momentum, eps);
-    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true>), grid, dim3(kBlock), 0, st, x, affine, save_mean, y, C, HW);
-    else hipLaunchKernelGGL((bn_apply_kernel<false>), grid, dim3(kBlock), 0, st, x, affine, save_mean, y, C, HW);
+                       save_invstd, running_mean, running_var, affine, C, HW, Ng, groups, (double)Ng * HW, momentum, eps);
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true>), grid, dim3(kBlock), 0, st, x, affine, save_mean, y, C, HW, Ng);
+    else hipLaunchKernelGGL((bn_apply_kernel<false>), grid, dim3(kBlock), 0, st, x, affine, save_mean, y, C, HW, Ng);
+    return launch_status();
+}
+
+extern "C" int mvster_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                                   float* save_invstd, float* running_mean, float* running_var, double* sums,
+                                   float* affine, int N, int C, int HW, float momentum, float eps, int relu,
+                                   mvster_stream_t stream) {
+    return mvster_bn_train_fwd_grouped(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, sums, affine, N, C,
+                                       HW, 1, momentum, eps, relu, stream);
+}
+
+extern "C" int mvster_bn_train_bwd_grouped(const float* dy, const float* x, const float* affine, const float* save_mean,
+                                           const float* save_invstd, float* dx, float* dgamma, float* dbeta, double* sums,
+                                           int N, int C, int HW, int groups, int relu, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(dy); MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(affine); MVSTER_REQUIRE_PTR(save_mean);
+    MVSTER_REQUIRE_PTR(save_invstd); MVSTER_REQUIRE_PTR(dx); MVSTER_REQUIRE_PTR(sums);
+    if (int rc = check_bn(N, C, HW)) return rc;
+    MVSTER_REQUIRE_SHAPE(groups > 0 && N % groups == 0);
+    const int Ng = N / groups;
+    const hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * groups, st) != hipSuccess) { (void)hipGetLastError(); return MVSTER_ERR_LAUNCH; }
+    dim3 grid(grid_for(HW, kBlock * kBnVec * kBnIters), C, N);
+    const double count = (double)Ng * HW;
+    if (relu) {
+        hipLaunchKernelGGL((bn_bwd_stats_kernel<true>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, C, HW, Ng);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, dx, dgamma, dbeta, C, HW, Ng, groups, count);
+    } else {
+        hipLaunchKernelGGL((bn_bwd_stats_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, C, HW, Ng);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, dx, dgamma, dbeta, C, HW, Ng, groups, count);
+    }
     return launch_status();
 }
 
 extern "C" int mvster_bn_train_bwd(const float* dy, const float* x, const float* affine, const float* save_mean,
                                    const float* save_invstd, float* dx, float* dgamma, float* dbeta, double* sums,
                                    int N, int C, int HW, int relu, mvster_stream_t stream) {
-    using namespace mvster;
-    MVSTER_REQUIRE_PTR(dy); MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(affine); MVSTER_REQUIRE_PTR(save_mean);
-    MVSTER_REQUIRE_PTR(save_invstd); MVSTER_REQUIRE_PTR(dx); MVSTER_REQUIRE_PTR(sums);
-    if (int rc = check_bn(N, C, HW)) return rc;
-    const hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { (void)hipGetLastError(); return MVSTER_ERR_LAUNCH; }
-    dim3 grid(grid_for(HW, kBlock * kBnVec * kBnIters), C, N);
-    const double count = (double)N * HW;
-    if (relu) {
-        hipLaunchKernelGGL((bn_bwd_stats_kernel<true>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, C, HW);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, dx, dgamma, dbeta, C, HW, count);
-    } else {
-        hipLaunchKernelGGL((bn_bwd_stats_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, C, HW);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, dx, dgamma, dbeta, C, HW, count);
-    }
-    return launch_status();
+    return mvster_bn_train_bwd_grouped(dy, x, affine, save_mean, save_invstd, dx, dgamma, dbeta, sums, N, C, HW, 1, relu, stream);
 }
 
 extern "C" int mvster_bn_train_fwd_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,

@@ -23,19 +23,20 @@ __all__ = ["MVS4net", "FPN4", "reg2d", "mono_depth_decoder"]
 # stock PyTorch building blocks (out of scope for HIP kernels; parameter names match the reference)
 # --------------------------------------------------------------------------------------------------
 class _BNReLUTrain(torch.autograd.Function):
-    """Training-mode BatchNorm (+ReLU) as two streaming HIP passes each way (csrc/batchnorm.hip)."""
+    """Training-mode BatchNorm (+ReLU) as two streaming HIP passes each way (csrc/batchnorm.hip).  ``groups`` > 1: the
+    batch is that many runs of consecutive samples, each normalised with its own statistics (NCHW only)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, groups=1):
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         dev = x.device
         nhwc = not x.is_contiguous()                     # _batch_norm admits only NCHW- or channels_last-dense inputs
         y = torch.empty_like(x)                          # preserve_format: same strides as x
-        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
-        save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
-        affine = torch.empty(C, 2, dtype=torch.float32, device=dev)
-        sums = torch.empty(C, 2, dtype=torch.float64, device=dev)
+        save_mean = torch.empty(groups, C, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(groups, C, dtype=torch.float32, device=dev)
+        affine = torch.empty(groups, C, 2, dtype=torch.float32, device=dev)
+        sums = torch.empty(groups, C, 2, dtype=torch.float64, device=dev)
         opt = lambda t: t.data_ptr() if t is not None else None
         with _on(dev):
             if nhwc:
@@ -43,19 +44,23 @@ class _BNReLUTrain(torch.autograd.Function):
                           save_mean.data_ptr(), save_invstd.data_ptr(), opt(running_mean), opt(running_var),
                           sums.data_ptr(), affine.data_ptr(), N * HW, C, float(momentum), float(eps),
                           1 if relu else 0, _stream(dev))
-            else:
+            elif groups == 1:
                 _lib.call("mvster_bn_train_fwd", x.data_ptr(), opt(weight), opt(bias), y.data_ptr(), save_mean.data_ptr(),
                           save_invstd.data_ptr(), opt(running_mean), opt(running_var), sums.data_ptr(), affine.data_ptr(),
                           N, C, HW, float(momentum), float(eps), 1 if relu else 0, _stream(dev))
+            else:
+                _lib.call("mvster_bn_train_fwd_grouped", x.data_ptr(), opt(weight), opt(bias), y.data_ptr(),
+                          save_mean.data_ptr(), save_invstd.data_ptr(), opt(running_mean), opt(running_var), sums.data_ptr(),
+                          affine.data_ptr(), N, C, HW, groups, float(momentum), float(eps), 1 if relu else 0, _stream(dev))
         ctx.save_for_backward(x, affine, save_mean, save_invstd)
-        ctx.cfg = (bool(relu), weight is not None, bias is not None, nhwc)
+        ctx.cfg = (bool(relu), weight is not None, bias is not None, nhwc, groups)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, affine, save_mean, save_invstd = ctx.saved_tensors
-        relu, has_w, has_b, nhwc = ctx.cfg
+        relu, has_w, has_b, nhwc, groups = ctx.cfg
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         dev = x.device
@@ -63,21 +68,27 @@ class _BNReLUTrain(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-        sums = torch.empty(C, 2, dtype=torch.float64, device=dev)
+        sums = torch.empty(groups, C, 2, dtype=torch.float64, device=dev)
         with _on(dev):
             if nhwc:
                 _lib.call("mvster_bn_train_bwd_nhwc", dy.data_ptr(), x.data_ptr(), affine.data_ptr(),
                           save_mean.data_ptr(), save_invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(),
                           dbeta.data_ptr(), sums.data_ptr(), N * HW, C, 1 if relu else 0, _stream(dev))
-            else:
+            elif groups == 1:
                 _lib.call("mvster_bn_train_bwd", dy.data_ptr(), x.data_ptr(), affine.data_ptr(), save_mean.data_ptr(),
                           save_invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), sums.data_ptr(),
                           N, C, HW, 1 if relu else 0, _stream(dev))
-        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None
+            else:
+                _lib.call("mvster_bn_train_bwd_grouped", dy.data_ptr(), x.data_ptr(), affine.data_ptr(), save_mean.data_ptr(),
+                          save_invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), sums.data_ptr(),
+                          N, C, HW, groups, 1 if relu else 0, _stream(dev))
+        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None
 
 
-def _batch_norm(bn, x, relu=False):
-    """Batch normalisation (+ optional ReLU) with the module's parameters/buffers.
+def _batch_norm(bn, x, relu=False, groups=1):
+    """Batch normalisation (+ optional ReLU) with the module's parameters/buffers.  ``groups`` > 1 (training mode): the
+    batch holds that many runs of consecutive samples that the reference would have pushed through one after the other
+    (the views of MVS4net.forward) -- each run gets its own statistics and the running statistics one update per run.
 
     Training mode on a HIP fp32 tensor, NCHW-contiguous or channels_last-dense: our two-pass kernels
     (``_BN_IMPL = "hip"``, default; one kernel family per layout, csrc/batchnorm.hip).
@@ -85,15 +96,22 @@ def _batch_norm(bn, x, relu=False):
     42 ms of a 128 ms training step); ATen's native kernels measured slower still (142 vs 128 ms per step).
     Eval mode (a per-channel affine) and every other case go through ``F.batch_norm`` (MIOpen on ROCm)."""
     training = bn.training or not bn.track_running_stats
+    if groups > 1 and training:
+        if x.shape[0] % groups:
+            raise ValueError("batch of %d samples does not split into %d statistic groups" % (x.shape[0], groups))
+        if not (_BN_IMPL == "hip" and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and bn.momentum is not None):
+            return torch.cat([_batch_norm(bn, part, relu) for part in x.chunk(groups, 0)], 0)
+    else:
+        groups = 1
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        bn.num_batches_tracked.add_(groups)
     dense_cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] in (4, 8, 16, 32, 64)
     fused = (_BN_IMPL == "hip" and training and x.is_cuda and x.dtype == torch.float32
              and (x.is_contiguous() or dense_cl) and bn.momentum is not None and x.dim() >= 3)
     if fused:
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
-        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu)
+        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu, groups)
     if x.is_cuda and _BN_IMPL == "native":
         y = torch.native_batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps)[0]
     else:
@@ -112,9 +130,9 @@ class _ConvBNReLU2d(nn.Module):
         self.conv = nn.Conv2d(cin, cout, kernel, stride=stride, padding=padding, bias=False)
         self.bn = nn.BatchNorm2d(cout, momentum=0.1)
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
         conv = self.conv
-        return _batch_norm(self.bn, _conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), relu=True)
+        return _batch_norm(self.bn, _conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), relu=True, groups=groups)
 
 
 def _conv3d_as_2d(conv, x2d, B, D):
@@ -312,10 +330,14 @@ class FPN4(nn.Module):
         self.dcn = False
         self.out_channels = [8 * b, 4 * b, 2 * b, b]
 
-    def forward(self, x):
-        skips = [self.conv0(x)]
-        for level in (self.conv1, self.conv2, self.conv3):
-            skips.append(level(skips[-1]))
+    def forward(self, x, groups=1):
+        """``groups`` > 1: ``x`` stacks that many views' batches along dim 0 and every BatchNorm normalises each view's
+        run with its own statistics -- one pass equal to the reference's one pass per view (models/MVS4Net.py:88-93)."""
+        skips = []
+        for level in (self.conv0, self.conv1, self.conv2, self.conv3):
+            for block in level:
+                x = block(x, groups)
+            skips.append(x)
         feat = skips[3]
         head_conv = lambda m, t: _conv2d(t, m.weight, m.bias, m.stride, m.padding)
         outs = {"stage1": head_conv(self.out1, feat)}
@@ -473,20 +495,23 @@ class MVS4net(nn.Module):
         # off by default: identical numerics either way, the conversion kernels cost ~1 % of a step
         self.channels_last_features = False
         self.batch_views_in_eval = True
+        self.batch_views_in_train = True
 
     def forward(self, imgs, proj_matrices, depth_values, filename=None):
         # step 1. feature extraction (stock PyTorch)
         features = []
-        if not self.training and self.batch_views_in_eval and len({tuple(i.shape) for i in imgs}) == 1:
-            # eval mode: BatchNorm uses its running statistics, so the N views are independent samples of one batch --
-            # one FPN pass over [N*B,3,H,W] instead of N passes (in training the reference normalises every view with
-            # its own batch statistics, so the views stay separate there)
+        batched = self.batch_views_in_eval if not self.training else (self.batch_views_in_train and not self.channels_last_features)
+        if batched and len({tuple(i.shape) for i in imgs}) == 1:
+            # one FPN pass over [N*B,3,H,W] instead of N passes.  Eval mode: BatchNorm uses its running statistics, so the
+            # views are independent samples of one batch.  Training mode: the reference normalises every view with its own
+            # batch statistics (one pass per view, models/MVS4Net.py:88-93) -- the BatchNorm kernels do the same inside the
+            # one pass (`groups`: statistics per run of B samples, running statistics updated view by view)
             stacked = torch.cat(list(imgs), 0)
             if self.channels_last_features:
                 stacked = stacked.contiguous(memory_format=torch.channels_last)
-            pyramid = self.feature(stacked)
             B = imgs[0].shape[0]
-            features = [{k: v[i * B:(i + 1) * B] for k, v in pyramid.items()} for i in range(len(imgs))]
+            pyramid = {k: v.split(B, 0) for k, v in self.feature(stacked, groups=len(imgs)).items()}
+            features = [{k: v[i] for k, v in pyramid.items()} for i in range(len(imgs))]
         else:
             for img in imgs:
                 if self.channels_last_features:

@@ -268,6 +268,21 @@ int mvster_bn_train_bwd(const float *dy, const float *x, const float *affine, co
                         const float *save_invstd, float *dx, float *dgamma, float *dbeta, double *sums, int N, int C,
                         int HW, int relu, mvster_stream_t stream);
 
+/* The same with `groups` statistic groups: the N samples are `groups` runs of N/groups consecutive samples, each run
+ * normalised with its own batch statistics, gamma/beta shared -- one launch for what the reference does as one
+ * FPN4 pass per view (models/MVS4Net.py:88-93: every view is a batch of its own in training mode).
+ *   save_mean, save_invstd : [groups,C]; affine : [groups,C,2]; sums : [groups,C,2] double scratch.
+ *   running_mean/var [C] receive the groups' updates one after the other, in group order (as the reference's successive
+ *   calls do); dgamma/dbeta [C] are summed over the groups.  groups = 1 is mvster_bn_train_fwd/bwd.
+ *   N % groups != 0 -> MVSTER_ERR_SHAPE. */
+int mvster_bn_train_fwd_grouped(const float *x, const float *gamma, const float *beta, float *y, float *save_mean,
+                                float *save_invstd, float *running_mean, float *running_var, double *sums,
+                                float *affine, int N, int C, int HW, int groups, float momentum, float eps, int relu,
+                                mvster_stream_t stream);
+int mvster_bn_train_bwd_grouped(const float *dy, const float *x, const float *affine, const float *save_mean,
+                                const float *save_invstd, float *dx, float *dgamma, float *dbeta, double *sums, int N,
+                                int C, int HW, int groups, int relu, mvster_stream_t stream);
+
 /* The same two operations on channels-last storage: x, y, dy, dx are [M = N*H*W, C] row-major (torch.channels_last),
  * C in {4, 8, 16, 32, 64} (else MVSTER_ERR_UNSUPPORTED).  All other arguments as above. */
 int mvster_bn_train_fwd_nhwc(const float *x, const float *gamma, const float *beta, float *y, float *save_mean,

@@ -69,3 +69,57 @@ def test_fused_bn_relu_matches_float64_batch_norm(shape, relu, mean_shift, chann
     ref.eval()
     yre = F.relu(ref(x.double())) if relu else ref(x.double())
     assert err(ye, yre) < 5e-6
+
+
+@pytest.mark.parametrize("shape,groups,relu", [((6, 8, 37, 53), 3, True), ((10, 16, 20, 24), 5, True), ((4, 64, 9, 11), 4, False),
+                                               ((5, 8, 64, 80), 5, True)])
+def test_grouped_statistics_equal_one_call_per_group(shape, groups, relu):
+    """`groups` runs of samples in one launch = the reference's one BatchNorm call per view, in view order
+    (models/MVS4Net.py:88-93): outputs, running statistics (updated group after group), num_batches_tracked and all
+    gradients against float64 torch evaluated run by run."""
+    from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net as m
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(shape) + groups)
+    C = shape[1]
+    x = torch.randn(shape, generator=g) * (0.5 + torch.rand(shape[0], C, 1, 1, generator=g)) + torch.randn(shape[0], 1, 1, 1, generator=g)
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(C, generator=g))
+        bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(0.5 + torch.rand(C, generator=g))
+    ref = nn.BatchNorm2d(C).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    w = torch.randn(shape, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = torch.cat([ref(part) for part in xr.chunk(groups, 0)], 0)
+    yr = F.relu(yr) if relu else yr
+    (yr * w.double()).sum().backward()
+
+    bn = bn.to(dev).train()
+    m._BN_IMPL = "hip"
+    xg = x.to(dev).requires_grad_(True)
+    calls = []
+    real_call = m._lib.call
+    m._lib.call = lambda name, *a: (calls.append(name), real_call(name, *a))[1]
+    try:
+        yg = m._batch_norm(bn, xg, relu=relu, groups=groups)
+    finally:
+        m._lib.call = real_call
+    assert calls == ["mvster_bn_train_fwd_grouped"]
+    (yg * w.to(dev)).sum().backward()
+
+    def err(a, b):
+        return float((a.detach().cpu().double() - b.detach()).abs().max()) / (float(b.detach().abs().max()) + 1e-30)
+
+    e = dict(y=err(yg, yr), dx=err(xg.grad, xr.grad), dw=err(bn.weight.grad, ref.weight.grad), db=err(bn.bias.grad, ref.bias.grad),
+             rm=err(bn.running_mean, ref.running_mean), rv=err(bn.running_var, ref.running_var))
+    print("    [parity] bn%s groups=%d: " % (tuple(shape), groups) + "  ".join("%s %.1e" % kv for kv in e.items()))
+    assert e["y"] < 2e-6 and e["rm"] < 1e-6 and e["rv"] < 1e-5
+    assert e["dx"] < 2e-5 and e["dw"] < 2e-5 and e["db"] < 2e-5
+    assert int(bn.num_batches_tracked) == groups
+    # a batch that does not split is refused, and eval mode ignores the groups
+    with pytest.raises(ValueError):
+        m._batch_norm(bn, torch.zeros(groups + 1, C, 4, 4, device=dev), groups=groups)
+    bn.eval()
+    assert torch.equal(m._batch_norm(bn, x.to(dev), relu=relu, groups=groups), m._batch_norm(bn, x.to(dev), relu=relu))

@@ -68,3 +68,41 @@ def test_fpn4_uses_the_fused_merge_and_matches_the_operator_path():
     for n in outs[True][2]:
         if "inner" in n:
             _close(outs[True][2][n], outs[False][2][n], "FPN4 grad " + n, rel=2e-3)
+
+
+def test_fpn4_one_pass_over_all_views_equals_one_pass_per_view():
+    """Training mode: FPN4 over the stacked views with per-view BatchNorm statistics (`groups`) vs the reference's loop,
+    one view at a time (models/MVS4Net.py:88-93): features, image / parameter gradients, running statistics."""
+    import copy
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    views, B = 3, 2
+    net_a = mvs4net.FPN4(8).to(dev).train()
+    net_b = copy.deepcopy(net_a)
+    imgs = [torch.rand(B, 3, 64, 96, device=dev) * (1.0 + v) for v in range(views)]
+    wts = None
+    res = []
+    for net, batched in ((net_a, True), (net_b, False)):
+        xs = [i.clone().requires_grad_(True) for i in imgs]
+        if batched:
+            pyr = {k: v.split(B, 0) for k, v in net(torch.cat(xs, 0), groups=views).items()}
+            feats = [{k: v[i] for k, v in pyr.items()} for i in range(views)]
+        else:
+            feats = [net(x) for x in xs]
+        if wts is None:
+            wts = [{k: torch.randn_like(v) for k, v in f.items()} for f in feats]
+        loss = sum((f[k] * w[k]).sum() for f, w in zip(feats, wts) for k in f)
+        loss.backward()
+        res.append((feats, [x.grad for x in xs], net))
+    (fa, ga, na), (fb, gb, nb) = res
+    for i in range(views):
+        for k in fa[i]:
+            _close(fa[i][k], fb[i][k], "view %d %s" % (i, k), rel=1e-4)
+        _close(ga[i], gb[i], "view %d d/d image" % i, rel=2e-3)
+    for (n, p), (_, q) in zip(na.named_parameters(), nb.named_parameters()):
+        _close(p.grad, q.grad, "grad " + n, rel=2e-3)
+    for (n, p), (_, q) in zip(na.named_buffers(), nb.named_buffers()):
+        if n.endswith("num_batches_tracked"):
+            assert int(p) == int(q) == views, n
+        else:
+            _close(p, q, "buffer " + n, rel=1e-5)

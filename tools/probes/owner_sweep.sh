@@ -7,6 +7,19 @@ CSRC=deep_reconstruction_with_epipolar_lines_mvster_amd/csrc
 OUT=tools/probes/build
 mkdir -p $OUT
 FLAGS="-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -I include -I $CSRC"
+# DEFS="-DMVSTER_C16_KPT=4 -DMVSTER_STAGED_KEEP_C=8" TAG=c16_kpt4 tools/probes/owner_sweep.sh builds one variant with those macros
+if [ -n "$DEFS" ]; then
+  objs=""
+  for f in cost_volume_fwd cost_volume_bwd cost_volume_binned; do
+    hipcc $FLAGS $DEFS -c $CSRC/$f.hip -o $OUT/${f}_$TAG.o &
+    objs="$objs $OUT/${f}_$TAG.o"
+  done
+  wait
+  others=$(ls $CSRC/build/*.o | grep -v "cost_volume_fwd.o\|cost_volume_bwd.o\|cost_volume_binned.o")
+  hipcc -shared --offload-arch=gfx950 -o $OUT/libmvster_$TAG.so $objs $others
+  echo built $OUT/libmvster_$TAG.so
+  exit 0
+fi
 for v in ${SWEEP:-"3 4" "4 3" "4 6" "5 2" "5 3"}; do
   set -- ${v//_/ }
   tag=lw$1_kpt$2${3:+_okpt$3}
