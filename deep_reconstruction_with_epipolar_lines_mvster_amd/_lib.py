@@ -54,6 +54,10 @@ PROTOTYPES = {
     "mvster_bn_train_bwd_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "mvster_fpn_merge_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_fpn_merge_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvster_conv_mfma_supported": [_i, _i, _i, _i],
+    "mvster_conv_mfma_workspace": [_i, _i, _i, _i, _i, _i, _i, _i],
+    "mvster_conv_mfma_fwd": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvster_conv_mfma_wgrad": [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_conv_direct_supported": [_i, _i, _i],
     "mvster_conv_direct_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_conv_direct_wgrad_workspace": [_i, _i, _i, _i, _i, _i],
@@ -64,7 +68,8 @@ PROTOTYPES = {
 }
 
 RESTYPES = {"mvster_cost_volume_bwd_workspace": _ll, "mvster_cost_volume_bwd_route_workspace": _ll,
-            "mvster_cost_volume_bin_counts": _ll, "mvster_conv_direct_wgrad_workspace": _ll}      # everything else returns the int status
+            "mvster_cost_volume_bin_counts": _ll, "mvster_conv_direct_wgrad_workspace": _ll,
+            "mvster_conv_mfma_workspace": _ll}      # everything else returns the int status
 
 MVSTER_OK = 0
 LAYOUT_NCHW = 0

@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(CSRC, "libmvster_hip.so")
-SOURCES = ["pose.hip", "layout.hip", "warp.hip", "cost_volume_fwd.hip", "cost_volume_bwd.hip", "cost_volume_scatter.hip", "cost_volume_binned.hip", "cost_volume_generic.hip", "regress.hip", "ranges.hip", "sinkhorn.hip", "batchnorm.hip", "fpn_merge.hip", "conv_direct.hip", "geofilter.hip"]
+SOURCES = ["pose.hip", "layout.hip", "warp.hip", "cost_volume_fwd.hip", "cost_volume_bwd.hip", "cost_volume_scatter.hip", "cost_volume_binned.hip", "cost_volume_generic.hip", "regress.hip", "ranges.hip", "sinkhorn.hip", "batchnorm.hip", "fpn_merge.hip", "conv_direct.hip", "conv_mfma.hip", "geofilter.hip"]
 HEADERS = ["mvster_device.h", "mvster_host.h", "cost_volume_common.h"]
 # -ffp-contract=off: fused multiply-adds are written explicitly where wanted, everything else rounds
 # like the reference's separate torch operators.

@@ -1,0 +1,482 @@
+// F2 / F3  many-channel convolutions of FPN4 / reg2d as implicit GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32:
+// f32 in, f32 accumulate -- bit-for-bit a k-ordered fmaf chain, so no precision is given up against the reference's fp32).
+// replaces: nn.Conv2d / the (1,3,3) and (3,3,3) nn.Conv3d layers (as conv2d over depth slices) with 16-64 output channels
+// -- FPN4 conv1.x/conv2.x/conv3.x, the 5x5 stride-2 level heads, out1/out2/out3 (models/mvs4net_utils.py:441-455,
+// 466-470), reg2d conv1..conv6 (models/mvs4net_utils.py:891-899) -- forward, input gradient (stride 1: the same kernel
+// on dy with flipped, transposed weights) and weight gradient.  NCHW fp32 in and out, "same"-style padding K/2.
+//
+// Why.  MIOpen runs these shapes (8-64 channels, 10^5-10^6 pixels) at 15-45 TFLOP/s forward and pays two layout transposes
+// around its NHWC implicit-GEMM weight-gradient kernels (tools/probes/conv_probe.py); the fp32 MFMA peak is 157 TFLOP/s.
+//
+// Forward, one workgroup = an 8 x 32 tile of output pixels x up to 64 output channels:
+//   D[co 32][pixel 32] += A[co][ci pair] * B[ci pair][pixel]     per tap (ky,kx) and pair of input channels
+//   A = weights, re-packed once per call to [ci][tap][co] and staged per CB input channels in LDS;
+//   B = the haloed input tile of those CB channels in LDS, plane-major exactly as NCHW delivers it: lane = pixel reads
+//       consecutive words (stride-2 layers: every other word, the second half-wave = the next channel sits on the odd banks).
+//   wave w owns tile rows 2w, 2w+1: 2 x NB accumulators of 32x32.  Stores: for each accumulator register a half-wave
+//   writes 32 consecutive pixels of one output-channel plane.
+// Weight gradient, dW[co][ci][ky][kx] = sum_p dy[co][p] x[ci][p*S + (ky,kx) - P]:
+//   D[co 32][(kx,ci) 32] += A[co][pixel pair] * B[pixel pair][(kx,ci)]   per ky; the GEMM's K runs over the pixels.
+//   Both tiles stay plane-major in LDS; a plane stride of (32/CIB) * odd words makes the 32 (kx,ci) columns of a lane group
+//   fall on 32 different banks.  Waves split the tile's rows, workgroups are persistent over tiles, partial sums are folded
+//   through LDS per workgroup and across workgroups by a second small kernel (no atomics: bitwise reproducible).
+#include "mvster_device.h"
+#include "mvster_host.h"
+
+namespace mvster {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMfTileW = 32;          // output pixels per MFMA column block
+constexpr int kMfRowsFwd = 8;         // output rows per forward tile: two per wave
+
+struct MfDims {
+    int N, Cin, Cout, H, W, Ho, Wo;   // x [N,Cin,H,W] -> y [N,Cout,Ho,Wo]
+    int CinPad, CoutPad;              // packed weights [CinPad][K*K][CoutPad]
+    int tiles_x, tiles_y;
+};
+
+__host__ __device__ constexpr int round_to_residue(int v, int mod, int res) { return v + ((res - v % mod) + mod) % mod; }
+
+// wp[ci][tap][co], zero-padded.  flip = 0: w is [Cout][Cin][KK] (a layer's own weights, forward).  flip = 1: w is
+// [Cin][Cout][KK] and the taps are mirrored (the input gradient of a stride-1 layer is the convolution of dy with these).
+__global__ void __launch_bounds__(kBlock)
+conv_mfma_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int KK, int CinPad, int CoutPad,
+                      int flip) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= CinPad * KK * CoutPad) return;
+    const int co = e % CoutPad, tap = (e / CoutPad) % KK, ci = e / (CoutPad * KK);
+    float v = 0.0f;
+    if (ci < Cin && co < Cout) v = flip ? w[((size_t)ci * Cout + co) * KK + (KK - 1 - tap)] : w[((size_t)co * Cin + ci) * KK + tap];
+    wp[e] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------ forward
+template <int KS, int S, int NB, int CB>
+struct FwdTile {
+    static constexpr int KK = KS * KS, P = KS / 2;
+    static constexpr int IN_H = (kMfRowsFwd - 1) * S + KS, IN_W = (kMfTileW - 1) * S + KS, PLANE = IN_H * IN_W;
+    // the two half-waves of an MFMA operand read consecutive channel planes: 32 banks apart (stride 1) / odd banks (stride 2)
+    static constexpr int PS = S == 1 ? round_to_residue(PLANE, 64, 32) : (PLANE | 1);
+    static constexpr int COW = NB * 32;
+    static constexpr int WPS = round_to_residue(KK * COW, 64, 32);
+};
+
+template <int KS, int S, int NB, int CB>
+__global__ void __launch_bounds__(kBlock)
+conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                     float* __restrict__ y, MfDims d) {
+    using T = FwdTile<KS, S, NB, CB>;
+    constexpr int KK = T::KK, P = T::P, IN_W = T::IN_W, PLANE = T::PLANE, PS = T::PS, COW = T::COW, WPS = T::WPS;
+    constexpr int PPW = CB / 4;                                    // input planes of a chunk per wave
+    constexpr int NI = (PLANE + kWave - 1) / kWave;                // elements of a plane per lane
+    constexpr int ROW4 = COW / 4, W4 = CB * KK * ROW4;             // packed weights of a chunk as float4s
+    constexpr int NW = (W4 + kBlock - 1) / kBlock;
+    static_assert(CB % 4 == 0, "planes are dealt to the four waves");
+    __shared__ float il[CB * PS];
+    __shared__ __attribute__((aligned(16))) float wl[CB * WPS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    int t = blockIdx.x;
+    const int tx = t % d.tiles_x;
+    t /= d.tiles_x;
+    const int ty = t % d.tiles_y, n = t / d.tiles_y;
+    const int co0 = blockIdx.y * COW;
+    const int gy0 = ty * kMfRowsFwd * S - P, gx0 = tx * kMfTileW * S - P;
+    const int HW = d.H * d.W;
+    const float* __restrict__ xn = x + (size_t)n * d.Cin * HW;
+
+    // this lane's elements of an input plane: the same window positions for every plane of every chunk
+    int goff[NI];                                                  // offset inside the plane, -1: outside the image / the window
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int idx = lane + kWave * k;
+        const int r = idx / IN_W, col = idx - r * IN_W;
+        const int gy = gy0 + r, gx = gx0 + col;
+        goff[k] = idx < PLANE && (unsigned)gy < (unsigned)d.H && (unsigned)gx < (unsigned)d.W ? gy * d.W + gx : -1;
+    }
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][nb][i] = 0.0f;
+
+    float vin[PPW][NI];
+    float4 vw[NW];
+    auto fetch = [&](int ci0) {                                    // global -> registers: in flight while the MFMAs of the previous chunk run
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) {
+            const int ci = ci0 + wave * PPW + pp;
+            const float* __restrict__ plane = xn + (size_t)ci * HW;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) vin[pp][k] = ci < d.Cin && goff[k] >= 0 ? plane[goff[k]] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int q = tid + kBlock * k;
+            const int row = q / ROW4, within = q - row * ROW4;     // row = c * KK + tap
+            vw[k] = q < W4 ? *reinterpret_cast<const float4*>(wp + ((size_t)ci0 * KK + row) * d.CoutPad + co0 + 4 * within)
+                           : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+    auto stage = [&]() {                                           // registers -> LDS
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp)
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int idx = lane + kWave * k;
+                if (idx < PLANE) il[(wave * PPW + pp) * PS + idx] = vin[pp][k];
+            }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int q = tid + kBlock * k;
+            const int row = q / ROW4, within = q - row * ROW4;
+            if (q < W4) *reinterpret_cast<float4*>(&wl[(row / KK) * WPS + (row % KK) * COW + 4 * within]) = vw[k];
+        }
+    };
+
+    fetch(0);
+    for (int ci0 = 0; ci0 < d.CinPad; ci0 += CB) {
+        if (ci0 > 0) __syncthreads();                              // the previous chunk has been consumed
+        stage();
+        __syncthreads();
+        if (ci0 + CB < d.CinPad) fetch(ci0 + CB);
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+            for (int c = 0; c < CB; c += 2) {
+                float a[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) a[nb] = wl[(c + h) * WPS + tap * COW + nb * 32 + p];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float b = il[(c + h) * PS + ((2 * wave + r) * S + ky) * IN_W + p * S + kx];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], b, acc[r][nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D: column (pixel) = lane & 31, row (output channel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int ox = tx * kMfTileW + p;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = ty * kMfRowsFwd + 2 * wave + r;
+        if (oy >= d.Ho || ox >= d.Wo) continue;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co0 + nb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (co < d.Cout)
+                    y[(((size_t)n * d.Cout + co) * d.Ho + oy) * d.Wo + ox] = acc[r][nb][i] + (bias != nullptr ? bias[co] : 0.0f);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- weight gradient
+struct MfWgDims {
+    int N, Cin, Cout, H, W, Ho, Wo;
+    int tiles_x, tiles_y, ntiles;
+    int ci_blocks;                    // blockIdx.y = co_block * ci_blocks + ci_block
+};
+
+template <int KS, int S, int CIB, int TH>
+struct WgTile {
+    static constexpr int P = KS / 2, RPW = TH / 4;                 // tile rows per wave
+    static constexpr int IN_H = (TH - 1) * S + KS, IN_W = (kMfTileW - 1) * S + KS, PLANE = IN_H * IN_W;
+    static constexpr int Q = 32 / CIB;                             // (kx, ci) columns of one MFMA span Q taps
+    static constexpr int PSX = (((PLANE + Q - 1) / Q) | 1) * Q;    // (32/CIB) * odd: the 32 columns fall on 32 banks
+    static constexpr int NBN = (KS * CIB + 31) / 32;               // column blocks per ky
+    static constexpr int DPS = TH * kMfTileW + 1;                  // dy plane stride, odd
+    static constexpr int XL = CIB * PSX + 64, DL = 32 * DPS;       // + slack: columns past the last tap read on (never stored)
+    static constexpr int E = KS * NBN * 1024;                      // partial sums per workgroup, MFMA-native order
+    static constexpr int LDS = (XL + DL) > E ? (XL + DL) : E;
+};
+
+template <int KS, int S, int CIB, int TH>
+__global__ void __launch_bounds__(kBlock)
+conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partials, MfWgDims d) {
+    using T = WgTile<KS, S, CIB, TH>;
+    constexpr int P = T::P, RPW = T::RPW, IN_W = T::IN_W, PLANE = T::PLANE, PSX = T::PSX, NBN = T::NBN, DPS = T::DPS, E = T::E;
+    constexpr int PPW = CIB / 4;                                   // x planes per wave
+    constexpr int NI = (PLANE + kWave - 1) / kWave;                // elements of an x plane per lane
+    constexpr int DPL = TH * kMfTileW, ND = DPL / kWave;           // dy plane of the tile, elements per lane; 8 planes per wave
+    static_assert(DPL % kWave == 0, "dy rows are dealt to whole waves");
+    extern __shared__ float lds[];                                 // T::LDS floats: x tile + dy tile, later the partial sums
+    float* __restrict__ xl = lds;
+    float* __restrict__ dyl = lds + T::XL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    const int cob = blockIdx.y / d.ci_blocks, cib = blockIdx.y - cob * d.ci_blocks;
+    const int co0 = cob * 32, ci0 = cib * CIB;
+    const int HW = d.H * d.W, HWo = d.Ho * d.Wo;
+
+    int boff[NBN];                                                 // lane's column (kx, ci) of block j inside the x tile
+#pragma unroll
+    for (int j = 0; j < NBN; ++j) {
+        const int f = j * 32 + p;
+        boff[j] = (f % CIB) * PSX + f / CIB;
+    }
+    f32x16 acc[KS][NBN];
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int j = 0; j < NBN; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ky][j][i] = 0.0f;
+
+    float vx[PPW][NI], vd[8][ND];
+    auto fetch = [&](int t) {                                      // global -> registers: in flight while the previous tile's MFMAs run
+        const int tx = t % d.tiles_x;
+        t /= d.tiles_x;
+        const int ty = t % d.tiles_y, n = t / d.tiles_y;
+        const int oy0 = ty * TH, ox0 = tx * kMfTileW;
+        const int gy0 = oy0 * S - P, gx0 = ox0 * S - P;
+        int goff[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int idx = lane + kWave * k;
+            const int r = idx / IN_W, col = idx - r * IN_W;
+            const int gy = gy0 + r, gx = gx0 + col;
+            goff[k] = idx < PLANE && (unsigned)gy < (unsigned)d.H && (unsigned)gx < (unsigned)d.W ? gy * d.W + gx : -1;
+        }
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) {
+            const int ci = ci0 + wave * PPW + pp;
+            const float* __restrict__ plane = x + ((size_t)n * d.Cin + ci) * HW;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) vx[pp][k] = ci < d.Cin && goff[k] >= 0 ? plane[goff[k]] : 0.0f;
+        }
+        int doff[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int idx = lane + kWave * k;
+            const int r = idx / kMfTileW, col = idx - r * kMfTileW;
+            doff[k] = oy0 + r < d.Ho && ox0 + col < d.Wo ? (oy0 + r) * d.Wo + ox0 + col : -1;
+        }
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int co = co0 + wave * 8 + pp;
+            const float* __restrict__ plane = dy + ((size_t)n * d.Cout + co) * HWo;
+#pragma unroll
+            for (int k = 0; k < ND; ++k) vd[pp][k] = co < d.Cout && doff[k] >= 0 ? plane[doff[k]] : 0.0f;
+        }
+    };
+    auto stage = [&]() {                                           // registers -> LDS
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp)
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int idx = lane + kWave * k;
+                if (idx < PLANE) xl[(wave * PPW + pp) * PSX + idx] = vx[pp][k];
+            }
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+            for (int k = 0; k < ND; ++k) dyl[(wave * 8 + pp) * DPS + lane + kWave * k] = vd[pp][k];
+    };
+
+    if ((int)blockIdx.x < d.ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
+        if (t != (int)blockIdx.x) __syncthreads();                 // the previous tile has been consumed
+        stage();
+        __syncthreads();
+        if (t + (int)gridDim.x < d.ntiles) fetch(t + gridDim.x);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
+#pragma unroll 4
+            for (int ox = 0; ox < kMfTileW; ox += 2) {
+                const float a = dyl[p * DPS + r * kMfTileW + ox + h];
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                    for (int j = 0; j < NBN; ++j) {
+                        const float b = xl[boff[j] + (r * S + ky) * IN_W + (ox + h) * S];
+                        acc[ky][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ky][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // fold the four waves' sums through LDS (wave after wave: plain reads and writes), then one coalesced store
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int j = 0; j < NBN; ++j)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float* __restrict__ slot = &lds[((ky * NBN + j) * 16 + i) * 64 + lane];
+                        *slot = w == 0 ? acc[ky][j][i] : *slot + acc[ky][j][i];
+                    }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ out = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * E;
+    for (int e = tid; e < E; e += kBlock) out[e] = lds[e];
+}
+
+// dW[co][ci][ky][kx] = sum over the workgroups' partial sums; E elements per (co block, ci block) in MFMA-native order:
+// e = ((ky * NBN + j) * 16 + reg) * 64 + lane.  A workgroup = 64 elements x 4 slices of the partials.
+__global__ void __launch_bounds__(kBlock)
+conv_mfma_wgrad_finish_kernel(const float* __restrict__ partials, float* __restrict__ dweight, int nparts, int E, int NBN, int KS,
+                              int CIB, int Cin, int Cout, int ci_blocks) {
+    __shared__ float red[kBlock];
+    const int grp = blockIdx.y;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (e < E)
+        for (int q = slice; q < nparts; q += 4) s += partials[((size_t)grp * nparts + q) * E + e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (slice != 0 || e >= E) return;
+    s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    const int lane = e & 63, reg = (e >> 6) & 15, kj = e >> 10;
+    const int j = kj % NBN, ky = kj / NBN;
+    const int cob = grp / ci_blocks, cib = grp - cob * ci_blocks;
+    const int co = cob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    const int f = j * 32 + (lane & 31);
+    const int kx = f / CIB, ci = cib * CIB + f % CIB;
+    if (kx < KS && ci < Cin && co < Cout) dweight[(((size_t)co * Cin + ci) * KS + ky) * KS + kx] = s;
+}
+
+static bool mfma_conv_shape_ok(int K, int stride) {
+    return (stride == 1 && (K == 1 || K == 3)) || (stride == 2 && (K == 3 || K == 5));
+}
+
+static int wgrad_cib(int Cin, int K) {
+    const int cib = Cin <= 8 ? 8 : Cin <= 16 ? 16 : 32;
+    return K == 5 && cib == 32 ? 16 : cib;                         // 5 x 5 columns of 32 channels: 400 accumulator registers
+}
+
+constexpr int kWgMaxGroupsGrid = 512;                              // persistent workgroups over all (co, ci) blocks together
+
+struct WgPlan {
+    int cib, th, ci_blocks, co_blocks, groups, nbn, E, grid_x, tiles_x, tiles_y, ntiles;
+};
+
+static WgPlan wgrad_plan(int N, int Cin, int Cout, int Ho, int Wo, int K, int stride) {
+    WgPlan pl;
+    pl.cib = wgrad_cib(Cin, K);
+    pl.th = stride == 1 ? 8 : 4;
+    pl.ci_blocks = (Cin + pl.cib - 1) / pl.cib;
+    pl.co_blocks = (Cout + 31) / 32;
+    pl.groups = pl.ci_blocks * pl.co_blocks;
+    pl.nbn = (K * pl.cib + 31) / 32;
+    pl.E = K * pl.nbn * 1024;
+    pl.tiles_x = (Wo + kMfTileW - 1) / kMfTileW;
+    pl.tiles_y = (Ho + pl.th - 1) / pl.th;
+    pl.ntiles = N * pl.tiles_x * pl.tiles_y;
+    int gx = kWgMaxGroupsGrid / pl.groups;
+    if (gx < 1) gx = 1;
+    pl.grid_x = pl.ntiles < gx ? pl.ntiles : gx;
+    return pl;
+}
+
+}  // namespace mvster
+
+extern "C" int mvster_conv_mfma_supported(int Cin, int Cout, int K, int stride) {
+    using namespace mvster;
+    return Cin > 0 && Cout > 0 && Cin <= 1024 && Cout <= 1024 && mfma_conv_shape_ok(K, stride) ? 1 : 0;
+}
+
+extern "C" long long mvster_conv_mfma_workspace(int N, int Cin, int Cout, int H, int W, int K, int stride, int op) {
+    using namespace mvster;
+    if (N <= 0 || H <= 0 || W <= 0 || !mvster_conv_mfma_supported(Cin, Cout, K, stride)) return 0;
+    if (op == MVSTER_CONV_OP_WGRAD) {
+        const int P = K / 2, Ho = (H + 2 * P - K) / stride + 1, Wo = (W + 2 * P - K) / stride + 1;
+        const WgPlan pl = wgrad_plan(N, Cin, Cout, Ho, Wo, K, stride);
+        return (long long)pl.groups * pl.grid_x * pl.E;
+    }
+    const int cb = stride == 1 ? 8 : 4;
+    return (long long)((Cin + cb - 1) / cb * cb) * K * K * ((Cout + 31) / 32 * 32);
+}
+
+#define MVSTER_MFMA_FWD(KS_, S_, NB_, CB_) \
+    hipLaunchKernelGGL((conv_mfma_fwd_kernel<KS_, S_, NB_, CB_>), grid, dim3(kBlock), 0, st, x, workspace, bias, y, d)
+
+extern "C" int mvster_conv_mfma_fwd(const float* x, const float* weight, const float* bias, float* y, float* workspace,
+                                    long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride,
+                                    int flip, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(weight); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(workspace);
+    MVSTER_REQUIRE_SHAPE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (long long)H * W <= kMaxPlane);
+    if (!mvster_conv_mfma_supported(Cin, Cout, K, stride)) return MVSTER_ERR_UNSUPPORTED;
+    MVSTER_REQUIRE_SHAPE(!flip || stride == 1);
+    MVSTER_REQUIRE_SHAPE(workspace_floats >= mvster_conv_mfma_workspace(N, Cin, Cout, H, W, K, stride, MVSTER_CONV_OP_FWD));
+    const int P = K / 2, cb = stride == 1 ? 8 : 4;
+    MfDims d;
+    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W;
+    d.Ho = (H + 2 * P - K) / stride + 1;
+    d.Wo = (W + 2 * P - K) / stride + 1;
+    d.CinPad = (Cin + cb - 1) / cb * cb;
+    d.CoutPad = (Cout + 31) / 32 * 32;
+    d.tiles_x = (d.Wo + kMfTileW - 1) / kMfTileW;
+    d.tiles_y = (d.Ho + kMfRowsFwd - 1) / kMfRowsFwd;
+    const long long tiles = (long long)N * d.tiles_x * d.tiles_y;
+    MVSTER_REQUIRE_SHAPE(tiles < (1LL << 31));
+    const hipStream_t st = as_stream(stream);
+    const int packed = d.CinPad * K * K * d.CoutPad;
+    hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
+                       K * K, d.CinPad, d.CoutPad, flip);
+    const bool two = d.CoutPad % 64 == 0;                          // 64 output channels per workgroup when they divide
+    const dim3 grid((unsigned)tiles, d.CoutPad / (two ? 64 : 32));
+    if (K == 1) { if (two) MVSTER_MFMA_FWD(1, 1, 2, 8); else MVSTER_MFMA_FWD(1, 1, 1, 8); }
+    else if (K == 3 && stride == 1) { if (two) MVSTER_MFMA_FWD(3, 1, 2, 8); else MVSTER_MFMA_FWD(3, 1, 1, 8); }
+    else if (K == 3) { if (two) MVSTER_MFMA_FWD(3, 2, 2, 4); else MVSTER_MFMA_FWD(3, 2, 1, 4); }
+    else { if (two) MVSTER_MFMA_FWD(5, 2, 2, 4); else MVSTER_MFMA_FWD(5, 2, 1, 4); }
+    return launch_status();
+}
+
+#define MVSTER_MFMA_WG(KS_, S_, CIB_, TH_)                                                                                   \
+    {                                                                                                                        \
+        constexpr int bytes = (int)sizeof(float) * WgTile<KS_, S_, CIB_, TH_>::LDS;                                          \
+        static_assert(bytes <= 160 * 1024, "tile does not fit the LDS");                                                    \
+        if (bytes > 64 * 1024 &&                                                                                             \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wgrad_kernel<KS_, S_, CIB_, TH_>),                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {                          \
+            (void)hipGetLastError();                                                                                         \
+            return MVSTER_ERR_LAUNCH;                                                                                        \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS_, S_, CIB_, TH_>), grid, dim3(kBlock), bytes, st, x, dy, workspace, d); \
+    }
+#define MVSTER_MFMA_WG_BY_CIB(KS_, S_, TH_)                 \
+    switch (pl.cib) {                                       \
+        case 8: MVSTER_MFMA_WG(KS_, S_, 8, TH_) break;      \
+        case 16: MVSTER_MFMA_WG(KS_, S_, 16, TH_) break;    \
+        default: MVSTER_MFMA_WG(KS_, S_, 32, TH_) break;    \
+    }
+
+extern "C" int mvster_conv_mfma_wgrad(const float* x, const float* dy, float* dweight, float* workspace,
+                                      long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride,
+                                      mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(dy); MVSTER_REQUIRE_PTR(dweight); MVSTER_REQUIRE_PTR(workspace);
+    MVSTER_REQUIRE_SHAPE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (long long)H * W <= kMaxPlane);
+    if (!mvster_conv_mfma_supported(Cin, Cout, K, stride)) return MVSTER_ERR_UNSUPPORTED;
+    MVSTER_REQUIRE_SHAPE(workspace_floats >= mvster_conv_mfma_workspace(N, Cin, Cout, H, W, K, stride, MVSTER_CONV_OP_WGRAD));
+    const int P = K / 2;
+    MfWgDims d;
+    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W;
+    d.Ho = (H + 2 * P - K) / stride + 1;
+    d.Wo = (W + 2 * P - K) / stride + 1;
+    const WgPlan pl = wgrad_plan(N, Cin, Cout, d.Ho, d.Wo, K, stride);
+    d.tiles_x = pl.tiles_x; d.tiles_y = pl.tiles_y; d.ntiles = pl.ntiles; d.ci_blocks = pl.ci_blocks;
+    const hipStream_t st = as_stream(stream);
+    const dim3 grid(pl.grid_x, pl.groups);
+    if (K == 1) { MVSTER_MFMA_WG_BY_CIB(1, 1, 8) }
+    else if (K == 3 && stride == 1) { MVSTER_MFMA_WG_BY_CIB(3, 1, 8) }
+    else if (K == 3) { MVSTER_MFMA_WG_BY_CIB(3, 2, 4) }
+    else {
+        if (pl.cib == 8) MVSTER_MFMA_WG(5, 2, 8, 4) else MVSTER_MFMA_WG(5, 2, 16, 4)
+    }
+    if (int rc = launch_status()) return rc;
+    hipLaunchKernelGGL(conv_mfma_wgrad_finish_kernel, dim3(grid_for(pl.E, 64), pl.groups), dim3(kBlock), 0, st, workspace, dweight,
+                       pl.grid_x, pl.E, pl.nbn, K, pl.cib, Cin, Cout, pl.ci_blocks);
+    return launch_status();
+}

@@ -170,21 +170,52 @@ class _ConvBNReLU3d(nn.Module):
         return _batch_norm(self.bn, _conv3d_as_2d(self.conv, x2d, B, D), relu=True)
 
 
+def _miopen_backward(dy, x, weight, stride, mask, bias_sizes=None):
+    K = weight.shape[2]
+    return torch.ops.aten.convolution_backward(dy, x, weight, bias_sizes, [stride, stride], [K // 2, K // 2], [1, 1], False,
+                                               [0, 0], 1, mask)
+
+
+def _mfma_workspace(lib, dev, N, Cin, Cout, H, W, K, stride, op):
+    need = lib.mvster_conv_mfma_workspace(N, Cin, Cout, H, W, K, stride, op)
+    return torch.empty(need, dtype=torch.float32, device=dev), need
+
+
 class _DirectConv2d(torch.autograd.Function):
-    """Stride-1 "same" convolution (K = 1 or 3) by the direct HIP kernels of csrc/conv_direct.hip: forward, input gradient
-    (the same kernel on dy with the flipped, transposed weight) and weight / bias gradient (tile partial sums, no atomics)."""
+    """"Same"-padded convolution (padding K // 2) whose three operations are routed separately (``route`` = implementation
+    of forward, input gradient, weight gradient; each "direct", "mfma" or "miopen"):
+    direct -- csrc/conv_direct.hip: stride 1, K = 1 or 3, few channels; forward, input gradient (the same kernel on dy with
+              the flipped, transposed weight) and weight / bias gradient (tile partial sums, no atomics);
+    mfma   -- csrc/conv_mfma.hip: implicit GEMMs on the fp32 matrix cores, (K, stride) in (1,1), (3,1), (3,2), (5,2);
+              forward, input gradient of the stride-1 layers, weight gradient;
+    miopen -- ATen's convolution / convolution_backward.
+    ``route`` None: the direct kernels with their own per-operation policy (the few-channel stride-1 layers)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, stride=1, route=None):
         N, Cin, H, W = x.shape
         Cout, _, K, _ = weight.shape
-        y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=x.device)
-        wt = weight.detach().permute(1, 2, 3, 0).contiguous()                  # [Cin, K, K, Cout]
-        with _on(x.device):
-            _lib.call("mvster_conv_direct_fwd", x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
-                      y.data_ptr(), N, Cin, Cout, H, W, K, _stream(x.device))
+        impl = "direct" if route is None else route[0]
+        dev = x.device
+        if impl == "miopen":
+            y = F.conv2d(x, weight, bias, stride, K // 2)
+        elif impl == "mfma":
+            Ho, Wo = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
+            y = torch.empty(N, Cout, Ho, Wo, dtype=torch.float32, device=dev)
+            ws, need = _mfma_workspace(_lib.load(), dev, N, Cin, Cout, H, W, K, stride, 0)
+            with _on(dev):
+                _lib.call("mvster_conv_mfma_fwd", x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                          y.data_ptr(), ws.data_ptr(), need, N, Cin, Cout, H, W, K, stride, 0, _stream(dev))
+        else:
+            y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=dev)
+            wt = weight.detach().permute(1, 2, 3, 0).contiguous()                  # [Cin, K, K, Cout]
+            with _on(dev):
+                _lib.call("mvster_conv_direct_fwd", x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                          y.data_ptr(), N, Cin, Cout, H, W, K, _stream(dev))
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.stride = stride
+        ctx.route = route
         return y
 
     @staticmethod
@@ -193,58 +224,103 @@ class _DirectConv2d(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         N, Cin, H, W = x.shape
         Cout, _, K, _ = weight.shape
+        stride, route = ctx.stride, ctx.route
         dy = dy.contiguous()
         dev = x.device
         dx = dweight = dbias = None
         lib = _lib.load()
+        if route is None:
+            dgrad = "direct" if Cin <= _DIRECT_MAX_DGRAD_CIN and lib.mvster_conv_direct_supported(Cout, Cin, K) else "miopen"
+            wgrad = "direct" if (Cout <= 8 or Cin * Cout <= _DIRECT_MAX_WGRAD_PRODUCT) and Cout in (1, 8, 16) else "miopen"
+        else:
+            dgrad, wgrad = route[1], route[2]
         with _on(dev):
             if ctx.needs_input_grad[0]:
-                if Cin <= _DIRECT_MAX_DGRAD_CIN and lib.mvster_conv_direct_supported(Cout, Cin, K):
+                if dgrad == "direct":
                     wt = weight.detach().flip(2, 3).permute(0, 2, 3, 1).contiguous()       # [Cout, K, K, Cin]
                     dx = torch.empty_like(x)
                     _lib.call("mvster_conv_direct_fwd", dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, Cout, Cin, H, W, K,
                               _stream(dev))
+                elif dgrad == "mfma":
+                    dx = torch.empty_like(x)
+                    ws, need = _mfma_workspace(lib, dev, N, Cout, Cin, H, W, K, 1, 0)
+                    _lib.call("mvster_conv_mfma_fwd", dy.data_ptr(), weight.data_ptr(), None, dx.data_ptr(), ws.data_ptr(), need,
+                              N, Cout, Cin, H, W, K, 1, 1, _stream(dev))
                 else:
-                    dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [K // 2, K // 2], [1, 1], False,
-                                                             [0, 0], 1, [True, False, False])[0]
-            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-                need = lib.mvster_conv_direct_wgrad_workspace(N, Cin, Cout, H, W, K)
-                if (Cout <= 8 or Cin * Cout <= _DIRECT_MAX_WGRAD_PRODUCT) and Cout in (1, 8, 16):
+                    dx = _miopen_backward(dy, x, weight, stride, [True, False, False])[0]
+            want_bias = ctx.has_bias and ctx.needs_input_grad[2]
+            if ctx.needs_input_grad[1] or want_bias:
+                if wgrad == "direct":
+                    need = lib.mvster_conv_direct_wgrad_workspace(N, Cin, Cout, H, W, K)
                     ws = torch.empty(need, dtype=torch.float32, device=dev)
                     dweight = torch.empty_like(weight)
                     dbias = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
                     _lib.call("mvster_conv_direct_wgrad", x.data_ptr(), dy.data_ptr(), dweight.data_ptr(),
                               dbias.data_ptr() if dbias is not None else None, ws.data_ptr(), need, N, Cin, Cout, H, W, K,
                               _stream(dev))
+                elif wgrad == "mfma":
+                    dweight = torch.empty_like(weight)
+                    ws, need = _mfma_workspace(lib, dev, N, Cin, Cout, H, W, K, stride, 1)
+                    _lib.call("mvster_conv_mfma_wgrad", x.data_ptr(), dy.data_ptr(), dweight.data_ptr(), ws.data_ptr(), need,
+                              N, Cin, Cout, H, W, K, stride, _stream(dev))
+                    dbias = dy.sum((0, 2, 3)) if want_bias else None
                 else:
-                    _, dweight, dbias = torch.ops.aten.convolution_backward(
-                        dy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [K // 2, K // 2], [1, 1], False, [0, 0], 1,
-                        [False, True, ctx.has_bias])
-        return dx, dweight, dbias
+                    _, dweight, dbias = _miopen_backward(dy, x, weight, stride, [False, True, ctx.has_bias],
+                                                         [Cout] if ctx.has_bias else None)
+        return dx, dweight, dbias, None, None
 
 
-_DIRECT_CONV = True          # small-channel stride-1 layers through csrc/conv_direct.hip; False: MIOpen (F.conv2d)
-# Routing policy, from per-operation timings against MIOpen at DTU resolution (tools/probes/conv_probe.py,
-# tools/probes/conv_split_probe.py; ms direct / MIOpen): forward 8->8 0.07/0.24, 4->8 (4 slices) 0.16/0.58, 64->8 0.34/0.75,
-# 8->1 1x1 0.09/0.49, but 64->16 0.26/0.26 and 48->16 0.62/0.60; input gradient 8->8 0.05/0.19, 4->8 0.14/0.67, 8->1
-# 0.04/0.30, but 64->8 0.56/0.35; weight gradient 8->8 0.18/0.28, 64->8 0.84/1.26, 16->8 0.08/0.13, 8->1 0.12/0.43, but
-# 16->16 0.19/0.13, 64->16 0.55/0.31.  MIOpen keeps what it does better: each of the three operations is routed on its own.
+_DIRECT_CONV = True          # few-channel stride-1 layers through csrc/conv_direct.hip; False: the other two
+_MFMA_CONV = True            # many-channel layers through csrc/conv_mfma.hip; False: MIOpen
+# Routing policy: every layer's three operations are routed separately on measured merit (tools/probes/conv_route_probe.py:
+# DTU resolution, the five views of FPN4 in one batch / the four depth slices of reg2d stage 4; ms direct / mfma / MIOpen):
+#   forward   8->8 0.29/0.50/0.83, 16->16 0.17/0.24/0.30, 64->8 1.55/2.75/2.97, 64->16 0.68/0.72/0.86, 48->16 0.41/0.46/0.50;
+#             32->32 -/0.13/0.15, 64->32 -/0.23/0.24, 96->32 -/0.25/0.28, 192->64 -/0.24/0.29, 1x1 64->64 -/0.04/0.07,
+#             stride 2: 8->16 -/0.16/0.26, 32->64 -/0.06/0.12, 5x5 8->16 -/0.37/0.52, 5x5 32->64 -/0.19/0.22
+#   input gradient  8->8 0.29/0.51/0.87, 16->16 0.19/0.25/0.34, 64->8 1.55/1.89/1.62, 64->16 0.97/0.58/0.62,
+#             32->32 -/0.16/0.15-0.95, 64->32 -/0.26/0.32, 96->32 -/0.28/0.37 (stride 2: MIOpen, no HIP kernel yet)
+#   weight gradient 8->8 0.58/0.63/1.43, 64->8 3.28/3.33/5.74, 16->16 0.73/0.32/0.53, 64->16 2.47/0.89/1.54,
+#             32->32 -/0.19/0.31, 64->32 -/0.31/1.15, 96->32 -/0.31/0.53, 5x5 s2 16->32 -/0.28/0.44; but 192->64 -/0.82/0.41
+# direct: one lane per pixel, Cout accumulators (few channels: bound by memory, which it streams best); mfma: implicit GEMM
+# on the fp32 matrix cores (80-110 TFLOP/s on the many-channel layers); MIOpen keeps what it still does better.
 _DIRECT_MAX_COUT = 16                # forward: few output channels ...
 _DIRECT_MAX_PRODUCT = 1024           # ... and Cin * Cout up to 64 x 16 (two pixels per lane from 16 accumulators up)
-_DIRECT_MAX_DGRAD_CIN = 16           # input gradient: Cin accumulators per lane
+_DIRECT_MAX_DGRAD_CIN = 16           # input gradient: Cin accumulators per lane (more when the layer has <= 8 output channels)
 _DIRECT_MAX_WGRAD_PRODUCT = 128      # weight gradient: Cout <= 8, or Cin * Cout up to this
+_MFMA_MAX_WGRAD_CIN = 96             # weight gradient: beyond, the (co, ci) block groups re-read the tiles too often
+
+
+def _conv_route(Cin, Cout, K, stride):
+    """(forward, input gradient, weight gradient) implementations for a "same"-padded layer, or None for plain F.conv2d."""
+    lib = _lib.load()
+    direct_ok = _DIRECT_CONV and stride == 1 and K in (1, 3) and Cout in (1, 3, 4, 8, 16)
+    mfma_ok = _MFMA_CONV and bool(lib.mvster_conv_mfma_supported(Cin, Cout, K, stride)) and Cout >= 16 and Cin >= 8
+    if direct_ok and Cin * Cout <= _DIRECT_MAX_PRODUCT:
+        fwd = "direct"
+    else:
+        fwd = "mfma" if mfma_ok else "miopen"
+    if direct_ok and (Cin <= _DIRECT_MAX_DGRAD_CIN or Cout <= 8) and lib.mvster_conv_direct_supported(Cout, Cin, K):
+        dgrad = "direct"
+    else:
+        dgrad = "mfma" if mfma_ok and stride == 1 else "miopen"
+    if direct_ok and (Cout <= 8 or Cin * Cout <= _DIRECT_MAX_WGRAD_PRODUCT):
+        wgrad = "direct"
+    else:
+        wgrad = "mfma" if mfma_ok and Cin <= _MFMA_MAX_WGRAD_CIN else "miopen"
+    route = (fwd, dgrad, wgrad)
+    return None if route == ("miopen", "miopen", "miopen") else route
 
 
 def _conv2d(x, weight, bias=None, stride=1, padding=0):
-    """F.conv2d, routed to the direct HIP kernels for the layers they are built for."""
+    """F.conv2d, routed per operation to the HIP kernels for the layers they are built for."""
     stride = (stride, stride) if isinstance(stride, int) else tuple(stride)
     padding = (padding, padding) if isinstance(padding, int) else tuple(padding)
     K = weight.shape[2]
-    if (_DIRECT_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
-            and weight.shape[2] == weight.shape[3] and K in (1, 3) and stride == (1, 1) and padding == (K // 2, K // 2)
-            and weight.shape[0] <= _DIRECT_MAX_COUT and weight.shape[0] in (1, 3, 4, 8, 16)
-            and weight.shape[0] * weight.shape[1] <= _DIRECT_MAX_PRODUCT):
-        return _DirectConv2d.apply(x, weight, bias)
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and weight.is_contiguous()
+            and weight.shape[2] == weight.shape[3] and stride[0] == stride[1] and padding == (K // 2, K // 2)):
+        route = _conv_route(weight.shape[1], weight.shape[0], K, stride[0])
+        if route is not None:
+            return _DirectConv2d.apply(x, weight, bias, stride[0], route)
     return F.conv2d(x, weight, bias, stride, padding)
 
 

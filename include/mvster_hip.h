@@ -294,6 +294,29 @@ int mvster_bn_train_bwd_nhwc(const float *dy, const float *x, const float *affin
                              long long M, int C, int relu, mvster_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * F2/F3  many-channel convolutions on the fp32 matrix cores (csrc/conv_mfma.hip), NCHW fp32, padding K/2:
+ * (K, stride) in {(1,1), (3,1), (3,2), (5,2)}.  replaces: nn.Conv2d / the nn.Conv3d layers run as conv2d over depth
+ * slices in FPN4 (models/mvs4net_utils.py:441-455,466-470) and reg2d (models/mvs4net_utils.py:891-899).
+ *   x [N,Cin,H,W]   y, dy [N,Cout,Ho,Wo] with Ho = (H + 2*(K/2) - K) / stride + 1 (same for Wo)
+ *   mvster_conv_mfma_fwd : y = conv(x, weight [Cout,Cin,K,K]) (+ bias [Cout], may be NULL).
+ *       flip = 1 (stride 1 only): `weight` is [Cin,Cout,K,K] and its taps are mirrored -- with x := dy of a stride-1
+ *       layer and Cin/Cout swapped this is that layer's input gradient.
+ *   mvster_conv_mfma_wgrad : dweight [Cout,Cin,K,K] = sum over n, pixels of dy (x) x-window.  (For a transposed
+ *       convolution layer pass x := the layer's dy, dy := the layer's x, Cin/Cout swapped: the result is its
+ *       [Cin,Cout,K,K] weight gradient.)  No atomics: bitwise reproducible.
+ *   workspace: mvster_conv_mfma_workspace(..., op) floats (packed weights / per-workgroup partial sums).
+ *   Unsupported (K, stride) -> MVSTER_ERR_UNSUPPORTED; mvster_conv_mfma_supported() says so beforehand. */
+#define MVSTER_CONV_OP_FWD 0
+#define MVSTER_CONV_OP_WGRAD 1
+int mvster_conv_mfma_supported(int Cin, int Cout, int K, int stride);
+long long mvster_conv_mfma_workspace(int N, int Cin, int Cout, int H, int W, int K, int stride, int op);
+int mvster_conv_mfma_fwd(const float *x, const float *weight, const float *bias, float *y, float *workspace,
+                         long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride, int flip,
+                         mvster_stream_t stream);
+int mvster_conv_mfma_wgrad(const float *x, const float *dy, float *dweight, float *workspace, long long workspace_floats,
+                           int N, int Cin, int Cout, int H, int W, int K, int stride, mvster_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * F3  top-down merge of the feature pyramid, fused:  y = bilinear_x2(feat, align_corners=True) + conv1x1(skip; weight, bias).
  * replaces: models/mvs4net_utils.py:490-505 (F.interpolate + innerK 1x1 convolution + add in FPN4.forward) and, in the
  * backward, ATen's atomic upsample backward, two convolution-gradient kernels with their transposes and a bias reduction.

@@ -52,29 +52,39 @@ def test_direct_conv_matches_torch(N, Cin, Cout, K, H, W, bias, monkeypatch):
 
 
 def test_routing_policy():
-    """_conv2d sends only stride-1 'same' K in {1,3} layers with few output channels to the direct kernels."""
+    """_conv2d routes each layer's three operations on their own: few-channel stride-1 layers to the direct kernels, the
+    many-channel / stride-2 / 5x5 ones to the matrix-core kernels, what neither does (or does worse) to MIOpen."""
+    route = mvs4net._conv_route
+    assert route(8, 8, 3, 1) == ("direct", "direct", "direct")              # FPN conv0.1
+    assert route(8, 1, 1, 1) == ("direct", "direct", "direct")              # reg2d prob
+    assert route(64, 8, 3, 1) == ("direct", "direct", "direct")             # FPN out4
+    assert route(64, 16, 3, 1) == ("direct", "mfma", "mfma")                # FPN out3
+    assert route(16, 16, 3, 1) == ("direct", "direct", "mfma")
+    assert route(32, 32, 3, 1) == ("mfma", "mfma", "mfma")
+    assert route(8, 16, 3, 2) == ("mfma", "miopen", "mfma")                 # stride 2: no HIP input gradient
+    assert route(32, 64, 5, 2) == ("mfma", "miopen", "mfma")
+    assert route(192, 64, 3, 1) == ("mfma", "mfma", "miopen")               # too many (co, ci) block groups for the weight gradient
+    assert route(8, 8, 5, 1) is None and route(8, 8, 7, 2) is None          # shapes nobody here handles: plain F.conv2d
     dev = torch.device("cuda:0")
     x = torch.randn(1, 8, 16, 16, device=dev)
     calls = []
     real = mvs4net._DirectConv2d.apply
-    mvs4net._DirectConv2d.apply = staticmethod(lambda *a: (calls.append(a[1].shape), real(*a))[1])
+    mvs4net._DirectConv2d.apply = staticmethod(lambda *a: (calls.append((tuple(a[1].shape), a[4])), real(*a))[1])
     try:
-        mvs4net._conv2d(x, torch.randn(8, 8, 3, 3, device=dev), None, 1, 1)            # direct
-        mvs4net._conv2d(x, torch.randn(16, 8, 3, 3, device=dev), None, 2, 1)           # stride 2: MIOpen
-        mvs4net._conv2d(x, torch.randn(64, 8, 3, 3, device=dev), None, 1, 1)           # many output channels: MIOpen
-        mvs4net._conv2d(x, torch.randn(8, 8, 5, 5, device=dev), None, 1, 2)            # 5x5: MIOpen
-        mvs4net._conv2d(x, torch.randn(1, 8, 1, 1, device=dev), torch.zeros(1, device=dev), 1, 0)   # direct
-        x64 = torch.randn(1, 64, 16, 16, device=dev)
-        mvs4net._conv2d(x64, torch.randn(8, 64, 3, 3, device=dev), None, 1, 1)         # 64 -> 8: direct (forward)
-        mvs4net._conv2d(x64, torch.randn(16, 64, 3, 3, device=dev), None, 1, 1)        # 64 -> 16: direct (two pixels per lane)
-        mvs4net._conv2d(torch.randn(1, 96, 16, 16, device=dev), torch.randn(16, 96, 3, 3, device=dev), None, 1, 1)   # Cin*Cout > 1024: MIOpen
+        mvs4net._conv2d(x, torch.randn(8, 8, 3, 3, device=dev), None, 1, 1)
+        mvs4net._conv2d(x, torch.randn(16, 8, 3, 3, device=dev), None, 2, 1)
+        mvs4net._conv2d(x, torch.randn(8, 8, 5, 5, device=dev), None, 1, 2)            # 5x5 stride 1: F.conv2d
+        mvs4net._conv2d(x, torch.randn(8, 8, 3, 3, device=dev), None, 1, 0)            # not "same" padding: F.conv2d
+        mvs4net._conv2d(x, torch.randn(1, 8, 1, 1, device=dev), torch.zeros(1, device=dev), 1, 0)
     finally:
         mvs4net._DirectConv2d.apply = real
-    assert [tuple(c) for c in calls] == [(8, 8, 3, 3), (1, 8, 1, 1), (8, 64, 3, 3), (16, 64, 3, 3)]
+    assert calls == [((8, 8, 3, 3), ("direct", "direct", "direct")), ((16, 8, 3, 3), ("mfma", "miopen", "mfma")),
+                     ((1, 8, 1, 1), ("direct", "direct", "direct"))]
 
 
 def test_mixed_backward_routing_matches_torch():
-    """64 -> 8 (FPN out4): direct forward, MIOpen for both gradients (the policy's mix) -- still the right numbers."""
+    """The policy's mixes through _conv2d: 64 -> 8 (FPN out4, all direct) and 16 -> 32 stride 2 (reg2d conv3: matrix-core
+    forward and weight gradient, MIOpen input gradient) -- still the right numbers."""
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5)
     x, w, gy = torch.randn(1, 64, 24, 70, generator=g), 0.2 * torch.randn(8, 64, 3, 3, generator=g), torch.randn(1, 8, 24, 70, generator=g)
@@ -82,5 +92,16 @@ def test_mixed_backward_routing_matches_torch():
     F.conv2d(ref[0], ref[1], None, 1, 1).backward(gy.double())
     got = [t.to(dev).requires_grad_(True) for t in (x, w)]
     mvs4net._conv2d(got[0], got[1], None, 1, 1).backward(gy.to(dev))
-    _close(got[0].grad, ref[0].grad, "64->8 dx (MIOpen)", rel=1e-4)
-    _close(got[1].grad, ref[1].grad, "64->8 dweight (MIOpen)", rel=1e-4)
+    _close(got[0].grad, ref[0].grad, "64->8 dx", rel=1e-4)
+    _close(got[1].grad, ref[1].grad, "64->8 dweight", rel=1e-4)
+    x, w = torch.randn(2, 16, 30, 44, generator=g), 0.2 * torch.randn(32, 16, 3, 3, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (x, w)]
+    want = F.conv2d(ref[0], ref[1], None, 2, 1)
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy.double())
+    got = [t.to(dev).requires_grad_(True) for t in (x, w)]
+    y = mvs4net._conv2d(got[0], got[1], None, 2, 1)
+    y.backward(gy.to(dev))
+    _close(y, want, "16->32 s2 y (mfma)", rel=1e-5)
+    _close(got[0].grad, ref[0].grad, "16->32 s2 dx (MIOpen)", rel=1e-4)
+    _close(got[1].grad, ref[1].grad, "16->32 s2 dweight (mfma)", rel=1e-4)

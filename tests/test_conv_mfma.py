@@ -1,0 +1,82 @@
+"""F2/F3 (GPU): the implicit-GEMM convolutions on the fp32 matrix cores (csrc/conv_mfma.hip) against torch's conv2d
+evaluated in float64 on the CPU -- forward, input gradient (stride 1) and weight gradient for the layer families of FPN4 /
+reg2d (models/mvs4net_utils.py:441-455,466-470,891-899): 1x1 and 3x3 stride 1, 3x3 and 5x5 stride 2, channel counts
+that do and do not fill the 32-wide MFMA blocks, sizes that are not tile multiples."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, what, rel):
+    want = want.detach().cpu().double()
+    err = float((got.detach().cpu().double() - want).abs().max())
+    scale = float(want.abs().max())
+    print("    [parity] %-44s max|err| %.3e (max|ref| %.3e)" % (what, err, scale))
+    assert err <= rel * scale + 1e-7, "%s: %.3e" % (what, err)
+
+
+CASES = [  # N, Cin, Cout, H, W, K, stride, bias
+    (2, 32, 32, 37, 53, 3, 1, False), (1, 64, 64, 18, 40, 3, 1, False), (2, 16, 16, 33, 70, 3, 1, True),
+    (1, 48, 16, 24, 40, 3, 1, False), (1, 96, 32, 17, 33, 3, 1, False), (1, 192, 64, 9, 20, 3, 1, False),
+    (2, 64, 32, 20, 31, 3, 1, False), (1, 64, 16, 40, 64, 3, 1, False), (3, 64, 64, 9, 13, 1, 1, False),
+    (1, 20, 40, 11, 35, 3, 1, True), (2, 8, 16, 32, 48, 3, 2, False), (1, 16, 32, 35, 67, 3, 2, False),
+    (1, 32, 64, 24, 40, 3, 2, False), (2, 8, 16, 40, 64, 5, 2, False), (1, 16, 32, 33, 61, 5, 2, False),
+    (1, 32, 64, 20, 36, 5, 2, True), (5, 32, 32, 16, 32, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,K,stride,bias", CASES)
+def test_mfma_convolution_matches_float64(N, Cin, Cout, H, W, K, stride, bias):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N * 1000 + Cin * 10 + Cout + H + K)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride, K // 2)
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy.double()).sum().backward()
+
+    route = ("mfma", "mfma" if stride == 1 else "miopen", "mfma")
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True) if bias else None
+    calls = []
+    real_call = mvs4net._lib.call
+    mvs4net._lib.call = lambda name, *a: (calls.append(name), real_call(name, *a))[1]
+    try:
+        yg = mvs4net._DirectConv2d.apply(xg, wg, bg, stride, route)
+        (yg * gy.to(dev)).sum().backward()
+    finally:
+        mvs4net._lib.call = real_call
+    assert calls == ["mvster_conv_mfma_fwd"] + (["mvster_conv_mfma_fwd"] if stride == 1 else []) + ["mvster_conv_mfma_wgrad"]
+    tag = "%dx%d s%d %d->%d N%d %dx%d" % (K, K, stride, Cin, Cout, N, H, W)
+    _close(yg, yr, tag + " forward", 2e-6)
+    _close(xg.grad, xr.grad, tag + " d/dx", 2e-6)
+    _close(wg.grad, wr.grad, tag + " d/dweight", 1e-5)
+    if bias:
+        _close(bg.grad, br.grad, tag + " d/dbias", 1e-5)
+
+
+def test_mfma_weight_gradient_is_bitwise_reproducible():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    x, w = torch.randn(2, 32, 64, 96, device=dev), torch.randn(32, 32, 3, 3, device=dev, requires_grad=True)
+    grads = []
+    for _ in range(2):
+        w.grad = None
+        y = mvs4net._DirectConv2d.apply(x, w, None, 1, ("mfma", "mfma", "mfma"))
+        y.square().sum().backward()
+        grads.append(w.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
+def test_unsupported_shapes_are_refused():
+    lib = mvs4net._lib.load()
+    assert lib.mvster_conv_mfma_supported(32, 32, 3, 1) == 1 and lib.mvster_conv_mfma_supported(32, 32, 5, 2) == 1
+    assert lib.mvster_conv_mfma_supported(32, 32, 5, 1) == 0 and lib.mvster_conv_mfma_supported(32, 32, 7, 2) == 0
+    assert lib.mvster_conv_mfma_supported(32, 32, 1, 2) == 0 and lib.mvster_conv_mfma_workspace(1, 32, 32, 8, 8, 7, 1, 0) == 0
