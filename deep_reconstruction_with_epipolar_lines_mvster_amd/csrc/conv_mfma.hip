@@ -38,16 +38,18 @@ struct MfDims {
 
 __host__ __device__ constexpr int round_to_residue(int v, int mod, int res) { return v + ((res - v % mod) + mod) % mod; }
 
-// wp[ci][tap][co], zero-padded.  flip = 0: w is [Cout][Cin][KK] (a layer's own weights, forward).  flip = 1: w is
+// wp[ci][tap][co], zero-padded.  mode 0: w is [Cout][Cin][KK] (a layer's own weights, forward).  mode 1: w is
 // [Cin][Cout][KK] and the taps are mirrored (the input gradient of a stride-1 layer is the convolution of dy with these).
+// mode 2: w is [Cin][Cout][KK], taps as they are (transposed convolution).
 __global__ void __launch_bounds__(kBlock)
 conv_mfma_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int KK, int CinPad, int CoutPad,
-                      int flip) {
+                      int mode) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= CinPad * KK * CoutPad) return;
     const int co = e % CoutPad, tap = (e / CoutPad) % KK, ci = e / (CoutPad * KK);
     float v = 0.0f;
-    if (ci < Cin && co < Cout) v = flip ? w[((size_t)ci * Cout + co) * KK + (KK - 1 - tap)] : w[((size_t)co * Cin + ci) * KK + tap];
+    if (ci < Cin && co < Cout)
+        v = mode == 0 ? w[((size_t)co * Cin + ci) * KK + tap] : w[((size_t)ci * Cout + co) * KK + (mode == 1 ? KK - 1 - tap : tap)];
     wp[e] = v;
 }
 
@@ -174,6 +176,141 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
                 if (co < d.Cout)
                     y[(((size_t)n * d.Cout + co) * d.Ho + oy) * d.Wo + ox] = acc[r][nb][i] + (bias != nullptr ? bias[co] : 0.0f);
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------- transposed convolution, stride 2
+// y[co][oy][ox] = sum over ci and the taps with (oy + P - ky), (ox + P - kx) even of w[ci][co][ky][kx] * x[ci][(oy+P-ky)/2][(ox+P-kx)/2]
+// -- reg2d's ConvTranspose3d (1,3,3) up-convolutions (models/mvs4net_utils.py:901-912) and the input gradient of every
+// stride-2 layer.  As a gather: an output pixel of row parity r and column parity q receives only the taps of matching
+// parity, and along a row the pixels of one column parity read CONSECUTIVE input columns -- so one MFMA column block is 32
+// output pixels of one parity (a 64-wide output tile holds both), and no multiplication by an inserted zero is ever issued.
+// Workgroup = 8 output rows x 64 output columns; wave w owns rows 2w (even), 2w+1 (odd) x both column parities.
+constexpr int kMfTrRows = 8, kMfTrInH = kMfTrRows / 2 + 2, kMfTrInW = kMfTileW + 2;
+
+template <int KS, int NB, int CB>
+struct TrTile {
+    static constexpr int KK = KS * KS, P = KS / 2;
+    static constexpr int PLANE = kMfTrInH * kMfTrInW;              // input rows oy0/2 - 1 .. oy0/2 + 4, columns ox0/2 - 1 .. ox0/2 + 32
+    static constexpr int PS = round_to_residue(PLANE, 64, 32);
+    static constexpr int COW = NB * 32;
+    static constexpr int WPS = round_to_residue(KK * COW, 64, 32);
+};
+
+template <int KS, int NB, int CB>
+__global__ void __launch_bounds__(kBlock)
+conv_mfma_transposed_kernel(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, MfDims d) {
+    using T = TrTile<KS, NB, CB>;
+    constexpr int KK = T::KK, P = T::P, IN_W = kMfTrInW, PLANE = T::PLANE, PS = T::PS, COW = T::COW, WPS = T::WPS;
+    constexpr int PPW = CB / 4, NI = (PLANE + kWave - 1) / kWave;
+    constexpr int ROW4 = COW / 4, W4 = CB * KK * ROW4, NW = (W4 + kBlock - 1) / kBlock;
+    __shared__ float il[CB * PS];
+    __shared__ __attribute__((aligned(16))) float wl[CB * WPS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    int t = blockIdx.x;
+    const int tx = t % d.tiles_x;
+    t /= d.tiles_x;
+    const int ty = t % d.tiles_y, n = t / d.tiles_y;
+    const int co0 = blockIdx.y * COW;
+    const int oy0 = ty * kMfTrRows, ox0 = tx * 2 * kMfTileW;       // even
+    const int gy0 = oy0 / 2 - 1, gx0 = ox0 / 2 - 1;
+    const int HW = d.H * d.W;
+    const float* __restrict__ xn = x + (size_t)n * d.Cin * HW;
+
+    int goff[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int idx = lane + kWave * k;
+        const int r = idx / IN_W, col = idx - r * IN_W;
+        const int gy = gy0 + r, gx = gx0 + col;
+        goff[k] = idx < PLANE && (unsigned)gy < (unsigned)d.H && (unsigned)gx < (unsigned)d.W ? gy * d.W + gx : -1;
+    }
+    f32x16 acc[2][2][NB];                                          // [row parity][column parity][co block]
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][q][nb][i] = 0.0f;
+
+    float vin[PPW][NI];
+    float4 vw[NW];
+    auto fetch = [&](int ci0) {
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) {
+            const int ci = ci0 + wave * PPW + pp;
+            const float* __restrict__ plane = xn + (size_t)ci * HW;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) vin[pp][k] = ci < d.Cin && goff[k] >= 0 ? plane[goff[k]] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int q = tid + kBlock * k;
+            const int row = q / ROW4, within = q - row * ROW4;
+            vw[k] = q < W4 ? *reinterpret_cast<const float4*>(wp + ((size_t)ci0 * KK + row) * d.CoutPad + co0 + 4 * within)
+                           : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp)
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int idx = lane + kWave * k;
+                if (idx < PLANE) il[(wave * PPW + pp) * PS + idx] = vin[pp][k];
+            }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int q = tid + kBlock * k;
+            const int row = q / ROW4, within = q - row * ROW4;
+            if (q < W4) *reinterpret_cast<float4*>(&wl[(row / KK) * WPS + (row % KK) * COW + 4 * within]) = vw[k];
+        }
+    };
+
+    fetch(0);
+    for (int ci0 = 0; ci0 < d.CinPad; ci0 += CB) {
+        if (ci0 > 0) __syncthreads();
+        stage();
+        __syncthreads();
+        if (ci0 + CB < d.CinPad) fetch(ci0 + CB);
+#pragma unroll
+        for (int c = 0; c < CB; c += 2) {
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int r = (ky + P) & 1;                        // the row parity this tap row feeds (oy0 is even)
+                const int lrow = wave + (r + P - ky) / 2 + 1;      // input row of output row 2*wave + r, inside the tile
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const int q = (kx + P) & 1;
+                    const int lcol = (q + P - kx) / 2 + 1;
+                    const float b = il[(c + h) * PS + lrow * IN_W + p + lcol];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float a = wl[(c + h) * WPS + (ky * KS + kx) * COW + nb * 32 + p];
+                        acc[r][q][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[r][q][nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + 2 * wave + r;
+        if (oy >= d.Ho) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ox = ox0 + 2 * p + q;
+            if (ox >= d.Wo) continue;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int co = co0 + nb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (co < d.Cout) y[(((size_t)n * d.Cout + co) * d.Ho + oy) * d.Wo + ox] = acc[r][q][nb][i];
+                }
+        }
     }
 }
 
@@ -423,13 +560,47 @@ extern "C" int mvster_conv_mfma_fwd(const float* x, const float* weight, const f
     const hipStream_t st = as_stream(stream);
     const int packed = d.CinPad * K * K * d.CoutPad;
     hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
-                       K * K, d.CinPad, d.CoutPad, flip);
+                       K * K, d.CinPad, d.CoutPad, flip ? 1 : 0);
     const bool two = d.CoutPad % 64 == 0;                          // 64 output channels per workgroup when they divide
     const dim3 grid((unsigned)tiles, d.CoutPad / (two ? 64 : 32));
     if (K == 1) { if (two) MVSTER_MFMA_FWD(1, 1, 2, 8); else MVSTER_MFMA_FWD(1, 1, 1, 8); }
     else if (K == 3 && stride == 1) { if (two) MVSTER_MFMA_FWD(3, 1, 2, 8); else MVSTER_MFMA_FWD(3, 1, 1, 8); }
     else if (K == 3) { if (two) MVSTER_MFMA_FWD(3, 2, 2, 4); else MVSTER_MFMA_FWD(3, 2, 1, 4); }
     else { if (two) MVSTER_MFMA_FWD(5, 2, 2, 4); else MVSTER_MFMA_FWD(5, 2, 1, 4); }
+    return launch_status();
+}
+
+#define MVSTER_MFMA_TR(KS_, NB_, CB_) \
+    hipLaunchKernelGGL((conv_mfma_transposed_kernel<KS_, NB_, CB_>), grid, dim3(kBlock), 0, st, x, workspace, y, d)
+
+extern "C" int mvster_conv_mfma_transposed(const float* x, const float* weight, float* y, float* workspace,
+                                           long long workspace_floats, int N, int Cin, int Cout, int H, int W, int Ho, int Wo,
+                                           int K, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(weight); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(workspace);
+    MVSTER_REQUIRE_SHAPE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && (long long)Ho * Wo <= kMaxPlane);
+    if (!(K == 3 || K == 5) || Cin > 1024 || Cout > 1024) return MVSTER_ERR_UNSUPPORTED;
+    const int P = K / 2;
+    // the stride-2 convolution that maps [Ho,Wo] back onto [H,W]: (Ho + 2P - K) / 2 + 1 = H
+    MVSTER_REQUIRE_SHAPE((Ho + 2 * P - K) / 2 + 1 == H && (Wo + 2 * P - K) / 2 + 1 == W);
+    const int cb = K == 3 ? 8 : 4;
+    MfDims d;
+    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.Ho = Ho; d.Wo = Wo;
+    d.CinPad = (Cin + cb - 1) / cb * cb;
+    d.CoutPad = (Cout + 31) / 32 * 32;
+    const long long packed = (long long)d.CinPad * K * K * d.CoutPad;
+    MVSTER_REQUIRE_SHAPE(workspace_floats >= packed);
+    d.tiles_x = (Wo + 2 * kMfTileW - 1) / (2 * kMfTileW);
+    d.tiles_y = (Ho + kMfTrRows - 1) / kMfTrRows;
+    const long long tiles = (long long)N * d.tiles_x * d.tiles_y;
+    MVSTER_REQUIRE_SHAPE(tiles < (1LL << 31));
+    const hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
+                       K * K, d.CinPad, d.CoutPad, 2);
+    const bool two = d.CoutPad % 64 == 0;
+    const dim3 grid((unsigned)tiles, d.CoutPad / (two ? 64 : 32));
+    if (K == 3) { if (two) MVSTER_MFMA_TR(3, 2, 8); else MVSTER_MFMA_TR(3, 1, 8); }
+    else { if (two) MVSTER_MFMA_TR(5, 2, 4); else MVSTER_MFMA_TR(5, 1, 4); }
     return launch_status();
 }
 

@@ -241,11 +241,17 @@ class _DirectConv2d(torch.autograd.Function):
                     dx = torch.empty_like(x)
                     _lib.call("mvster_conv_direct_fwd", dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, Cout, Cin, H, W, K,
                               _stream(dev))
-                elif dgrad == "mfma":
+                elif dgrad == "mfma" and stride == 1:
                     dx = torch.empty_like(x)
                     ws, need = _mfma_workspace(lib, dev, N, Cout, Cin, H, W, K, 1, 0)
                     _lib.call("mvster_conv_mfma_fwd", dy.data_ptr(), weight.data_ptr(), None, dx.data_ptr(), ws.data_ptr(), need,
                               N, Cout, Cin, H, W, K, 1, 1, _stream(dev))
+                elif dgrad == "mfma":                      # stride 2: dy scattered back = a transposed convolution, as a gather
+                    dx = torch.empty_like(x)
+                    Hd, Wd = dy.shape[2], dy.shape[3]
+                    ws, need = _mfma_workspace(lib, dev, N, Cout, Cin, Hd, Wd, K, 2, 0)
+                    _lib.call("mvster_conv_mfma_transposed", dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), ws.data_ptr(), need,
+                              N, Cout, Cin, Hd, Wd, H, W, K, _stream(dev))
                 else:
                     dx = _miopen_backward(dy, x, weight, stride, [True, False, False])[0]
             want_bias = ctx.has_bias and ctx.needs_input_grad[2]
@@ -268,6 +274,56 @@ class _DirectConv2d(torch.autograd.Function):
                     _, dweight, dbias = _miopen_backward(dy, x, weight, stride, [False, True, ctx.has_bias],
                                                          [Cout] if ctx.has_bias else None)
         return dx, dweight, dbias, None, None
+
+
+class _MfmaConvTranspose2d(torch.autograd.Function):
+    """conv_transpose2d(x, weight [Cin,Cout,3,3], stride 2, padding 1, output_padding 1) on the matrix cores
+    (csrc/conv_mfma.hip): forward = the gather-form transposed kernel, input gradient = the stride-2 forward kernel on dy,
+    weight gradient = the weight-gradient kernel with the roles of x and dy swapped."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        N, Cin, H, W = x.shape
+        Cout, K = weight.shape[1], weight.shape[2]
+        dev = x.device
+        y = torch.empty(N, Cout, 2 * H, 2 * W, dtype=torch.float32, device=dev)
+        ws, need = _mfma_workspace(_lib.load(), dev, N, Cin, Cout, H, W, K, 2, 0)
+        with _on(dev):
+            _lib.call("mvster_conv_mfma_transposed", x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), need,
+                      N, Cin, Cout, H, W, 2 * H, 2 * W, K, _stream(dev))
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        Cout, K = weight.shape[1], weight.shape[2]
+        dy = dy.contiguous()
+        dev = x.device
+        lib = _lib.load()
+        dx = dweight = None
+        with _on(dev):
+            if ctx.needs_input_grad[0]:                    # a stride-2 convolution of dy with the same [Cin,Cout,K,K] array
+                dx = torch.empty_like(x)
+                ws, need = _mfma_workspace(lib, dev, N, Cout, Cin, 2 * H, 2 * W, K, 2, 0)
+                _lib.call("mvster_conv_mfma_fwd", dy.data_ptr(), weight.data_ptr(), None, dx.data_ptr(), ws.data_ptr(), need,
+                          N, Cout, Cin, 2 * H, 2 * W, K, 2, 0, _stream(dev))
+            if ctx.needs_input_grad[1]:
+                dweight = torch.empty_like(weight)
+                ws, need = _mfma_workspace(lib, dev, N, Cout, Cin, 2 * H, 2 * W, K, 2, 1)
+                _lib.call("mvster_conv_mfma_wgrad", dy.data_ptr(), x.data_ptr(), dweight.data_ptr(), ws.data_ptr(), need,
+                          N, Cout, Cin, 2 * H, 2 * W, K, 2, _stream(dev))
+        return dx, dweight
+
+
+def _conv_transpose2d_x2(x, weight):
+    """F.conv_transpose2d(x, weight, stride=2, padding=1, output_padding=1) for a 3x3 kernel: reg2d's up-convolutions."""
+    if (_MFMA_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and weight.is_contiguous()
+            and tuple(weight.shape[2:]) == (3, 3)):
+        return _MfmaConvTranspose2d.apply(x, weight)
+    return F.conv_transpose2d(x, weight, None, stride=2, padding=1, output_padding=1)
 
 
 _DIRECT_CONV = True          # few-channel stride-1 layers through csrc/conv_direct.hip; False: the other two
@@ -302,7 +358,7 @@ def _conv_route(Cin, Cout, K, stride):
     if direct_ok and (Cin <= _DIRECT_MAX_DGRAD_CIN or Cout <= 8) and lib.mvster_conv_direct_supported(Cout, Cin, K):
         dgrad = "direct"
     else:
-        dgrad = "mfma" if mfma_ok and stride == 1 else "miopen"
+        dgrad = "mfma" if mfma_ok and (stride == 1 or K in (3, 5)) else "miopen"
     if direct_ok and (Cout <= 8 or Cin * Cout <= _DIRECT_MAX_WGRAD_PRODUCT):
         wgrad = "direct"
     else:
@@ -471,8 +527,11 @@ class reg2d(nn.Module):
     @staticmethod
     def _up(seq, x2d):
         deconv, bn = seq[0], seq[1]
-        y = F.conv_transpose2d(x2d, deconv.weight[:, :, 0], None, stride=deconv.stride[1:], padding=deconv.padding[1:],
-                               output_padding=deconv.output_padding[1:])
+        if deconv.stride[1:] == (2, 2) and deconv.padding[1:] == (1, 1) and deconv.output_padding[1:] == (1, 1):
+            y = _conv_transpose2d_x2(x2d, deconv.weight[:, :, 0].contiguous())
+        else:
+            y = F.conv_transpose2d(x2d, deconv.weight[:, :, 0], None, stride=deconv.stride[1:], padding=deconv.padding[1:],
+                                   output_padding=deconv.output_padding[1:])
         return _batch_norm(bn, y, relu=True)
 
     def forward_slices(self, x):

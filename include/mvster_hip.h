@@ -315,6 +315,15 @@ int mvster_conv_mfma_fwd(const float *x, const float *weight, const float *bias,
                          mvster_stream_t stream);
 int mvster_conv_mfma_wgrad(const float *x, const float *dy, float *dweight, float *workspace, long long workspace_floats,
                            int N, int Cin, int Cout, int H, int W, int K, int stride, mvster_stream_t stream);
+/* Transposed convolution, stride 2, K in {3, 5}, padding K/2, as a gather (no zero insertion):
+ *   y[co][oy][ox] = sum_{ci, taps of matching parity} weight[ci][co][ky][kx] * x[ci][(oy + K/2 - ky)/2][(ox + K/2 - kx)/2]
+ * replaces: reg2d's nn.ConvTranspose3d (1,3,3) up-convolutions (models/mvs4net_utils.py:901-912, as conv_transpose2d over
+ * depth slices) and -- with x := dy, weight := the layer's [Cout,Cin,K,K] weights, Cin/Cout swapped -- the input gradient of
+ * the stride-2 layers.  x [N,Cin,H,W], weight [Cin,Cout,K,K], y [N,Cout,Ho,Wo]; [Ho,Wo] must map back onto [H,W] under the
+ * stride-2 convolution ((Ho + 2*(K/2) - K)/2 + 1 == H: Ho = 2H or 2H-1), else MVSTER_ERR_BAD_SHAPE.
+ * workspace: mvster_conv_mfma_workspace(N, Cin, Cout, H, W, K, 2, MVSTER_CONV_OP_FWD) floats. */
+int mvster_conv_mfma_transposed(const float *x, const float *weight, float *y, float *workspace, long long workspace_floats,
+                                int N, int Cin, int Cout, int H, int W, int Ho, int Wo, int K, mvster_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * F3  top-down merge of the feature pyramid, fused:  y = bilinear_x2(feat, align_corners=True) + conv1x1(skip; weight, bias).

@@ -61,8 +61,8 @@ def test_routing_policy():
     assert route(64, 16, 3, 1) == ("direct", "mfma", "mfma")                # FPN out3
     assert route(16, 16, 3, 1) == ("direct", "direct", "mfma")
     assert route(32, 32, 3, 1) == ("mfma", "mfma", "mfma")
-    assert route(8, 16, 3, 2) == ("mfma", "miopen", "mfma")                 # stride 2: no HIP input gradient
-    assert route(32, 64, 5, 2) == ("mfma", "miopen", "mfma")
+    assert route(8, 16, 3, 2) == ("mfma", "mfma", "mfma")                   # stride 2: input gradient = the transposed kernel
+    assert route(32, 64, 5, 2) == ("mfma", "mfma", "mfma")
     assert route(192, 64, 3, 1) == ("mfma", "mfma", "miopen")               # too many (co, ci) block groups for the weight gradient
     assert route(8, 8, 5, 1) is None and route(8, 8, 7, 2) is None          # shapes nobody here handles: plain F.conv2d
     dev = torch.device("cuda:0")
@@ -78,13 +78,13 @@ def test_routing_policy():
         mvs4net._conv2d(x, torch.randn(1, 8, 1, 1, device=dev), torch.zeros(1, device=dev), 1, 0)
     finally:
         mvs4net._DirectConv2d.apply = real
-    assert calls == [((8, 8, 3, 3), ("direct", "direct", "direct")), ((16, 8, 3, 3), ("mfma", "miopen", "mfma")),
+    assert calls == [((8, 8, 3, 3), ("direct", "direct", "direct")), ((16, 8, 3, 3), ("mfma", "mfma", "mfma")),
                      ((1, 8, 1, 1), ("direct", "direct", "direct"))]
 
 
 def test_mixed_backward_routing_matches_torch():
     """The policy's mixes through _conv2d: 64 -> 8 (FPN out4, all direct) and 16 -> 32 stride 2 (reg2d conv3: matrix-core
-    forward and weight gradient, MIOpen input gradient) -- still the right numbers."""
+    forward, transposed-kernel input gradient, weight gradient) -- still the right numbers."""
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5)
     x, w, gy = torch.randn(1, 64, 24, 70, generator=g), 0.2 * torch.randn(8, 64, 3, 3, generator=g), torch.randn(1, 8, 24, 70, generator=g)
@@ -103,5 +103,5 @@ def test_mixed_backward_routing_matches_torch():
     y = mvs4net._conv2d(got[0], got[1], None, 2, 1)
     y.backward(gy.to(dev))
     _close(y, want, "16->32 s2 y (mfma)", rel=1e-5)
-    _close(got[0].grad, ref[0].grad, "16->32 s2 dx (MIOpen)", rel=1e-4)
+    _close(got[0].grad, ref[0].grad, "16->32 s2 dx (mfma, transposed)", rel=1e-4)
     _close(got[1].grad, ref[1].grad, "16->32 s2 dweight (mfma)", rel=1e-4)

@@ -42,7 +42,7 @@ def test_mfma_convolution_matches_float64(N, Cin, Cout, H, W, K, stride, bias):
     gy = torch.randn(yr.shape, generator=g)
     (yr * gy.double()).sum().backward()
 
-    route = ("mfma", "mfma" if stride == 1 else "miopen", "mfma")
+    route = ("mfma", "mfma", "mfma")
     xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
     bg = b.to(dev).requires_grad_(True) if bias else None
     calls = []
@@ -53,13 +53,50 @@ def test_mfma_convolution_matches_float64(N, Cin, Cout, H, W, K, stride, bias):
         (yg * gy.to(dev)).sum().backward()
     finally:
         mvs4net._lib.call = real_call
-    assert calls == ["mvster_conv_mfma_fwd"] + (["mvster_conv_mfma_fwd"] if stride == 1 else []) + ["mvster_conv_mfma_wgrad"]
+    assert calls == ["mvster_conv_mfma_fwd", "mvster_conv_mfma_fwd" if stride == 1 else "mvster_conv_mfma_transposed",
+                     "mvster_conv_mfma_wgrad"]
     tag = "%dx%d s%d %d->%d N%d %dx%d" % (K, K, stride, Cin, Cout, N, H, W)
     _close(yg, yr, tag + " forward", 2e-6)
     _close(xg.grad, xr.grad, tag + " d/dx", 2e-6)
     _close(wg.grad, wr.grad, tag + " d/dweight", 1e-5)
     if bias:
         _close(bg.grad, br.grad, tag + " d/dbias", 1e-5)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 32, 9, 13), (1, 32, 16, 20, 33), (4, 16, 8, 18, 40), (1, 24, 40, 7, 70)])
+def test_mfma_transposed_convolution_matches_float64(N, Cin, Cout, H, W):
+    """reg2d's up-convolutions (ConvTranspose3d (1,3,3), stride 2, padding 1, output_padding 1, models/mvs4net_utils.py:901-912)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N + Cin + Cout + H + W)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, stride=2, padding=1, output_padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy.double()).sum().backward()
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    calls = []
+    real_call = mvs4net._lib.call
+    mvs4net._lib.call = lambda name, *a: (calls.append(name), real_call(name, *a))[1]
+    try:
+        yg = mvs4net._conv_transpose2d_x2(xg, wg)
+        (yg * gy.to(dev)).sum().backward()
+    finally:
+        mvs4net._lib.call = real_call
+    assert calls == ["mvster_conv_mfma_transposed", "mvster_conv_mfma_fwd", "mvster_conv_mfma_wgrad"]
+    tag = "convT 3x3 s2 %d->%d N%d %dx%d" % (Cin, Cout, N, H, W)
+    _close(yg, yr, tag + " forward", 2e-6)
+    _close(xg.grad, xr.grad, tag + " d/dx", 2e-6)
+    _close(wg.grad, wr.grad, tag + " d/dweight", 1e-5)
+
+
+def test_transposed_kernel_refuses_sizes_that_do_not_map_back():
+    dev = torch.device("cuda:0")
+    lib = mvs4net._lib.load()
+    x, w, y = torch.zeros(1, 8, 5, 5, device=dev), torch.zeros(8, 8, 3, 3, device=dev), torch.zeros(1, 8, 12, 12, device=dev)
+    ws = torch.zeros(8 * 9 * 32, device=dev)
+    rc = lib.mvster_conv_mfma_transposed(x.data_ptr(), w.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), 1, 8, 8, 5, 5, 12, 12, 3, None)
+    assert rc not in (0, mvs4net._lib.MVSTER_ERR_UNSUPPORTED)                 # MVSTER_ERR_BAD_SHAPE
 
 
 def test_mfma_weight_gradient_is_bitwise_reproducible():
