@@ -125,6 +125,13 @@ def _range_miss(hypo_depth, depth_gt, inverse):
     return near.sum(1) == 0
 
 
+def _masked_mean(values, mask):
+    """``values[mask].mean()`` without the boolean gather: no data-dependent shape, hence no host synchronisation (the
+    step stays capturable in a HIP graph); an empty mask gives NaN either way."""
+    m = mask.to(values.dtype)
+    return (values * m).sum() / m.sum()
+
+
 def _stage_items(inputs):
     return [(k, inputs[k]) for k in inputs.keys() if "stage" in k]
 
@@ -145,10 +152,10 @@ def _losses(inputs, depth_gt_ms, mask_ms, kwargs):
         mask = mask_ms[key] > 0.5
         gt = depth_gt_ms[key]
         if mono and stage_idx != 0:
-            l1 = F.l1_loss(out["mono_depth"][mask], gt[mask], reduction="mean")
+            l1 = _masked_mean((out["mono_depth"] - gt).abs(), mask)          # F.l1_loss(mono[mask], gt[mask])
         else:
             l1 = torch.zeros((), dtype=torch.float32, device=dev)
-        misses.append(_range_miss(out["hypo_depth"], gt, inverse)[mask].float().mean())
+        misses.append(_masked_mean(_range_miss(out["hypo_depth"], gt, inverse).float(), mask))
         ot = _stage_loss(gt, out["hypo_depth"], out["attn_weight"], mask, ot_iter, ot_eps, ot_continous)
         l1s.append(l1)
         ots.append(ot)
@@ -169,5 +176,6 @@ def Blend_loss(inputs, depth_gt_ms, mask_ms, **kwargs):
     depth_min = kwargs.get("depth_min", 1)
     total, l1s, ots, misses, (pred, gt, mask) = _losses(inputs, depth_gt_ms, mask_ms, kwargs)
     scale = 128 / (depth_max - depth_min)[:, None, None]
-    abs_err = (pred * scale - gt * scale)[mask].abs()
-    return total, l1s, ots, misses, abs_err.mean(), (abs_err <= 3).float().mean() * 100, (abs_err <= 1).float().mean() * 100
+    abs_err = (pred * scale - gt * scale).abs()
+    return (total, l1s, ots, misses, _masked_mean(abs_err, mask), _masked_mean((abs_err <= 3).float(), mask) * 100,
+            _masked_mean((abs_err <= 1).float(), mask) * 100)

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--eval", action="store_true")
     ap.add_argument("--benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (slow MIOpen find)")
     ap.add_argument("--bn", default="hip", choices=["hip", "native", "miopen"])
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (forward, loss, backward, Adam) in one HIP graph and time its replays: the "
+                         "step without the ~1600 kernel launches' host-side cost")
     ap.add_argument("--ddp", action="store_true",
                     help="wrap the model in DistributedDataParallel over RCCL like train_mvs4.py:562-570 (one process per GPU; "
                          "start with torch.distributed.run, or alone for a one-rank group)")
@@ -56,7 +59,7 @@ def main():
         model.to_channels_last(True)
     if args.ddp:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=args.graph)
     imgs = [torch.rand(B, 3, H, W, device=dev) for _ in range(N)]
     proj = {}
     for k, sc in enumerate((8, 4, 2, 1)):
@@ -83,6 +86,22 @@ def main():
     step = eval_step if args.eval else train_step
     step()
     torch.cuda.synchronize()
+    if args.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # allocator and MIOpen warm-up on the capture side stream
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        if not args.eval:
+            opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            step()
+        step = graph.replay
+        step()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -92,8 +111,8 @@ def main():
         import torch.distributed as dist
         print("DDP over %s, %d rank(s)" % (dist.get_backend(), dist.get_world_size()), flush=True)
         dist.destroy_process_group()
-    print("e2e %s step (bn=%s): %dx%d, N=%d, B=%d, channels_last=%s: %.1f ms/step = %.2f ref-views/s, peak mem %.1f GB"
-          % ("eval" if args.eval else "train", args.bn, W, H, N, B, args.channels_last, dt * 1e3, B / dt,
+    print("e2e %s step%s (bn=%s): %dx%d, N=%d, B=%d, channels_last=%s: %.1f ms/step = %.2f ref-views/s, peak mem %.1f GB"
+          % ("eval" if args.eval else "train", " as one HIP graph" if args.graph else "", args.bn, W, H, N, B, args.channels_last, dt * 1e3, B / dt,
              torch.cuda.max_memory_allocated() / 1e9), flush=True)
 
 
