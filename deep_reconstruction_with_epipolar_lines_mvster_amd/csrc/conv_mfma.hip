@@ -458,11 +458,145 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
     for (int e = tid; e < E; e += kBlock) out[e] = lds[e];
 }
 
+// Weight gradient of the 3x3 stride-1 layers with <= 8 output channels (FPN4 conv0.1, out4; reg2d conv0).  With the output
+// channels on an MFMA axis, 8 of 32 rows would do work.  Here the roles are swapped and the three tap rows ride along:
+//   D[(kx,ci) 32][(ky,co) 32] += A[(kx,ci)][pixel pair] * B[pixel pair][(ky,co)],   B = dy[co] shifted up by ky rows
+// (dW[co][ci][ky][kx] = sum_p' dy[co][p' - ky rows] x[ci][p' + kx], p' running over the INPUT tile's pixels), so 24 of the 32
+// columns are live and one pass over the input tile's rows feeds all nine taps.  Tile = 6 output rows (8 input rows: two per
+// wave); the dy tile carries 3 zero rows above and 2 below for the shifted reads that fall outside it.
+constexpr int kPkRows = 6, kPkDyRows = kPkRows + 5;
+
+template <int CIB>
+struct WgPackTile {
+    static constexpr int IN_H = kPkRows + 2, IN_W = kMfTileW + 2, PLANE = IN_H * IN_W;
+    static constexpr int Q = 32 / CIB;
+    static constexpr int PSX = (((PLANE + Q - 1) / Q) | 1) * Q;
+    static constexpr int NBN = (3 * CIB + 31) / 32;
+    static constexpr int DPS = kPkDyRows * kMfTileW + 1;           // odd
+    static constexpr int XL = CIB * PSX + 64, DL = 8 * DPS;
+    static constexpr int E = NBN * 1024;
+    static constexpr int LDS = (XL + DL) > E ? (XL + DL) : E;
+};
+
+template <int CIB>
+__global__ void __launch_bounds__(kBlock)
+conv_mfma_wgrad_packed_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partials, MfWgDims d) {
+    using T = WgPackTile<CIB>;
+    constexpr int IN_H = T::IN_H, IN_W = T::IN_W, PLANE = T::PLANE, PSX = T::PSX, NBN = T::NBN, DPS = T::DPS, E = T::E;
+    constexpr int PPW = CIB / 4, NI = (PLANE + kWave - 1) / kWave;
+    constexpr int DPL = kPkRows * kMfTileW, ND = DPL / kWave;      // dy plane of the tile: 192 pixels, 3 per lane; 2 planes per wave
+    static_assert(IN_H % 4 == 0 && DPL % kWave == 0, "input rows and dy pixels are dealt evenly");
+    extern __shared__ float lds[];
+    float* __restrict__ xl = lds;
+    float* __restrict__ dyl = lds + T::XL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    const int ci0 = blockIdx.y * CIB;
+    const int HW = d.H * d.W;
+
+    int aoff[NBN];                                                 // lane's row (kx, ci) of block j inside the x tile
+#pragma unroll
+    for (int j = 0; j < NBN; ++j) {
+        const int f = j * 32 + p;
+        aoff[j] = (f % CIB) * PSX + f / CIB;
+    }
+    const int boff = (p & 7) * DPS + (3 - (p >> 3)) * kMfTileW;    // lane's column (ky, co): dy plane co, shifted up by ky rows
+    f32x16 acc[NBN];
+#pragma unroll
+    for (int j = 0; j < NBN; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+    for (int e = tid; e < T::DL; e += kBlock) dyl[e] = 0.0f;       // the padding rows stay zero for the whole kernel
+
+    float vx[PPW][NI], vd[2][ND];
+    auto fetch = [&](int t) {
+        const int tx = t % d.tiles_x;
+        t /= d.tiles_x;
+        const int ty = t % d.tiles_y, n = t / d.tiles_y;
+        const int oy0 = ty * kPkRows, ox0 = tx * kMfTileW;
+        int goff[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int idx = lane + kWave * k;
+            const int r = idx / IN_W, col = idx - r * IN_W;
+            const int gy = oy0 - 1 + r, gx = ox0 - 1 + col;
+            goff[k] = idx < PLANE && (unsigned)gy < (unsigned)d.H && (unsigned)gx < (unsigned)d.W ? gy * d.W + gx : -1;
+        }
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) {
+            const int ci = ci0 + wave * PPW + pp;
+            const float* __restrict__ plane = x + ((size_t)n * d.Cin + ci) * HW;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) vx[pp][k] = ci < d.Cin && goff[k] >= 0 ? plane[goff[k]] : 0.0f;
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int co = wave * 2 + pp;
+            const float* __restrict__ plane = dy + ((size_t)n * d.Cout + co) * HW;
+#pragma unroll
+            for (int k = 0; k < ND; ++k) {
+                const int idx = lane + kWave * k;
+                const int r = idx / kMfTileW, col = idx - r * kMfTileW;
+                vd[pp][k] = co < d.Cout && oy0 + r < d.H && ox0 + col < d.W ? plane[(oy0 + r) * d.W + ox0 + col] : 0.0f;
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp)
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int idx = lane + kWave * k;
+                if (idx < PLANE) xl[(wave * PPW + pp) * PSX + idx] = vx[pp][k];
+            }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int k = 0; k < ND; ++k) dyl[(wave * 2 + pp) * DPS + 3 * kMfTileW + lane + kWave * k] = vd[pp][k];
+    };
+
+    if ((int)blockIdx.x < d.ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
+        __syncthreads();                                           // the previous tile has been consumed (first: dyl is zeroed)
+        stage();
+        __syncthreads();
+        if (t + (int)gridDim.x < d.ntiles) fetch(t + gridDim.x);
+#pragma unroll
+        for (int rr = 0; rr < IN_H / 4; ++rr) {
+            const int r = wave * (IN_H / 4) + rr;                  // input-tile row; output row r - ky
+#pragma unroll 4
+            for (int ox = 0; ox < kMfTileW; ox += 2) {
+                // input column of output pixel ox under tap kx is ox + kx: the tap offset sits in aoff
+                const float b = dyl[boff + r * kMfTileW + ox + h];
+#pragma unroll
+                for (int j = 0; j < NBN; ++j) {
+                    const float a = xl[aoff[j] + r * IN_W + ox + h];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < NBN; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float* __restrict__ slot = &lds[(j * 16 + i) * 64 + lane];
+                    *slot = w == 0 ? acc[j][i] : *slot + acc[j][i];
+                }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ out = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * E;
+    for (int e = tid; e < E; e += kBlock) out[e] = lds[e];
+}
+
 // dW[co][ci][ky][kx] = sum over the workgroups' partial sums; E elements per (co block, ci block) in MFMA-native order:
 // e = ((ky * NBN + j) * 16 + reg) * 64 + lane.  A workgroup = 64 elements x 4 slices of the partials.
 __global__ void __launch_bounds__(kBlock)
 conv_mfma_wgrad_finish_kernel(const float* __restrict__ partials, float* __restrict__ dweight, int nparts, int E, int NBN, int KS,
-                              int CIB, int Cin, int Cout, int ci_blocks) {
+                              int CIB, int Cin, int Cout, int ci_blocks, int packed) {
     __shared__ float red[kBlock];
     const int grp = blockIdx.y;
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
@@ -474,6 +608,13 @@ conv_mfma_wgrad_finish_kernel(const float* __restrict__ partials, float* __restr
     if (slice != 0 || e >= E) return;
     s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
     const int lane = e & 63, reg = (e >> 6) & 15, kj = e >> 10;
+    if (packed) {                                                  // rows = (kx, ci) of block kj, columns = (ky, co): see the packed kernel
+        const int co = lane & 7, ky = (lane & 31) >> 3;
+        const int f = kj * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int kx = f / CIB, ci = grp * CIB + f % CIB;
+        if (ky < KS && kx < KS && ci < Cin && co < Cout) dweight[(((size_t)co * Cin + ci) * KS + ky) * KS + kx] = s;
+        return;
+    }
     const int j = kj % NBN, ky = kj / NBN;
     const int cob = grp / ci_blocks, cib = grp - cob * ci_blocks;
     const int co = cob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -495,17 +636,19 @@ constexpr int kWgMaxGroupsGrid = 512;                              // persistent
 
 struct WgPlan {
     int cib, th, ci_blocks, co_blocks, groups, nbn, E, grid_x, tiles_x, tiles_y, ntiles;
+    bool packed;                      // <= 8 output channels, 3x3 stride 1: conv_mfma_wgrad_packed_kernel
 };
 
 static WgPlan wgrad_plan(int N, int Cin, int Cout, int Ho, int Wo, int K, int stride) {
     WgPlan pl;
     pl.cib = wgrad_cib(Cin, K);
-    pl.th = stride == 1 ? 8 : 4;
+    pl.packed = K == 3 && stride == 1 && Cout <= 8;
+    pl.th = pl.packed ? kPkRows : stride == 1 ? 8 : 4;
     pl.ci_blocks = (Cin + pl.cib - 1) / pl.cib;
     pl.co_blocks = (Cout + 31) / 32;
     pl.groups = pl.ci_blocks * pl.co_blocks;
     pl.nbn = (K * pl.cib + 31) / 32;
-    pl.E = K * pl.nbn * 1024;
+    pl.E = (pl.packed ? 1 : K) * pl.nbn * 1024;
     pl.tiles_x = (Wo + kMfTileW - 1) / kMfTileW;
     pl.tiles_y = (Ho + pl.th - 1) / pl.th;
     pl.ntiles = N * pl.tiles_x * pl.tiles_y;
@@ -616,6 +759,17 @@ extern "C" int mvster_conv_mfma_transposed(const float* x, const float* weight, 
         }                                                                                                                    \
         hipLaunchKernelGGL((conv_mfma_wgrad_kernel<KS_, S_, CIB_, TH_>), grid, dim3(kBlock), bytes, st, x, dy, workspace, d); \
     }
+#define MVSTER_MFMA_WG_PACKED(CIB_)                                                                                      \
+    {                                                                                                                    \
+        constexpr int bytes = (int)sizeof(float) * WgPackTile<CIB_>::LDS;                                                \
+        if (bytes > 64 * 1024 &&                                                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wgrad_packed_kernel<CIB_>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {                      \
+            (void)hipGetLastError();                                                                                     \
+            return MVSTER_ERR_LAUNCH;                                                                                    \
+        }                                                                                                                \
+        hipLaunchKernelGGL((conv_mfma_wgrad_packed_kernel<CIB_>), grid, dim3(kBlock), bytes, st, x, dy, workspace, d);   \
+    }
 #define MVSTER_MFMA_WG_BY_CIB(KS_, S_, TH_)                 \
     switch (pl.cib) {                                       \
         case 8: MVSTER_MFMA_WG(KS_, S_, 8, TH_) break;      \
@@ -640,7 +794,14 @@ extern "C" int mvster_conv_mfma_wgrad(const float* x, const float* dy, float* dw
     d.tiles_x = pl.tiles_x; d.tiles_y = pl.tiles_y; d.ntiles = pl.ntiles; d.ci_blocks = pl.ci_blocks;
     const hipStream_t st = as_stream(stream);
     const dim3 grid(pl.grid_x, pl.groups);
-    if (K == 1) { MVSTER_MFMA_WG_BY_CIB(1, 1, 8) }
+    if (pl.packed) {
+        switch (pl.cib) {
+            case 8: MVSTER_MFMA_WG_PACKED(8) break;
+            case 16: MVSTER_MFMA_WG_PACKED(16) break;
+            default: MVSTER_MFMA_WG_PACKED(32) break;
+        }
+    }
+    else if (K == 1) { MVSTER_MFMA_WG_BY_CIB(1, 1, 8) }
     else if (K == 3 && stride == 1) { MVSTER_MFMA_WG_BY_CIB(3, 1, 8) }
     else if (K == 3) { MVSTER_MFMA_WG_BY_CIB(3, 2, 4) }
     else {
@@ -648,6 +809,6 @@ extern "C" int mvster_conv_mfma_wgrad(const float* x, const float* dy, float* dw
     }
     if (int rc = launch_status()) return rc;
     hipLaunchKernelGGL(conv_mfma_wgrad_finish_kernel, dim3(grid_for(pl.E, 64), pl.groups), dim3(kBlock), 0, st, workspace, dweight,
-                       pl.grid_x, pl.E, pl.nbn, K, pl.cib, Cin, Cout, pl.ci_blocks);
+                       pl.grid_x, pl.E, pl.nbn, K, pl.cib, Cin, Cout, pl.ci_blocks, pl.packed ? 1 : 0);
     return launch_status();
 }

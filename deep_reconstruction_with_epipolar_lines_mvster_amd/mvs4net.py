@@ -335,7 +335,7 @@ _MFMA_CONV = True            # many-channel layers through csrc/conv_mfma.hip; F
 #             stride 2: 8->16 -/0.16/0.26, 32->64 -/0.06/0.12, 5x5 8->16 -/0.37/0.52, 5x5 32->64 -/0.19/0.22
 #   input gradient  8->8 0.29/0.51/0.87, 16->16 0.19/0.25/0.34, 64->8 1.55/1.89/1.62, 64->16 0.97/0.58/0.62,
 #             32->32 -/0.16/0.15-0.95, 64->32 -/0.26/0.32, 96->32 -/0.28/0.37 (stride 2: MIOpen, no HIP kernel yet)
-#   weight gradient 8->8 0.58/0.63/1.43, 64->8 3.28/3.33/5.74, 16->16 0.73/0.32/0.53, 64->16 2.47/0.89/1.54,
+#   weight gradient 3->8 0.56/0.36/0.87, 8->8 0.56/0.38/1.39, 64->8 3.27/1.78/5.64, 16->16 0.73/0.32/0.53, 64->16 2.47/0.89/1.54,
 #             32->32 -/0.19/0.31, 64->32 -/0.31/1.15, 96->32 -/0.31/0.53, 5x5 s2 16->32 -/0.28/0.44; but 192->64 -/0.82/0.41
 # direct: one lane per pixel, Cout accumulators (few channels: bound by memory, which it streams best); mfma: implicit GEMM
 # on the fp32 matrix cores (80-110 TFLOP/s on the many-channel layers); MIOpen keeps what it still does better.
@@ -359,7 +359,9 @@ def _conv_route(Cin, Cout, K, stride):
         dgrad = "direct"
     else:
         dgrad = "mfma" if mfma_ok and (stride == 1 or K in (3, 5)) else "miopen"
-    if direct_ok and (Cout <= 8 or Cin * Cout <= _DIRECT_MAX_WGRAD_PRODUCT):
+    if _MFMA_CONV and K == 3 and stride == 1 and Cout in (4, 8) and Cin >= 3:
+        wgrad = "mfma"                 # <= 8 output channels: the tap rows packed next to them on the MFMA's column axis
+    elif direct_ok and (Cout <= 8 or Cin * Cout <= _DIRECT_MAX_WGRAD_PRODUCT):
         wgrad = "direct"
     else:
         wgrad = "mfma" if mfma_ok and Cin <= _MFMA_MAX_WGRAD_CIN else "miopen"

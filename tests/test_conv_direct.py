@@ -55,9 +55,9 @@ def test_routing_policy():
     """_conv2d routes each layer's three operations on their own: few-channel stride-1 layers to the direct kernels, the
     many-channel / stride-2 / 5x5 ones to the matrix-core kernels, what neither does (or does worse) to MIOpen."""
     route = mvs4net._conv_route
-    assert route(8, 8, 3, 1) == ("direct", "direct", "direct")              # FPN conv0.1
+    assert route(8, 8, 3, 1) == ("direct", "direct", "mfma")                # FPN conv0.1: packed-tap weight gradient
     assert route(8, 1, 1, 1) == ("direct", "direct", "direct")              # reg2d prob
-    assert route(64, 8, 3, 1) == ("direct", "direct", "direct")             # FPN out4
+    assert route(64, 8, 3, 1) == ("direct", "direct", "mfma")               # FPN out4
     assert route(64, 16, 3, 1) == ("direct", "mfma", "mfma")                # FPN out3
     assert route(16, 16, 3, 1) == ("direct", "direct", "mfma")
     assert route(32, 32, 3, 1) == ("mfma", "mfma", "mfma")
@@ -78,12 +78,12 @@ def test_routing_policy():
         mvs4net._conv2d(x, torch.randn(1, 8, 1, 1, device=dev), torch.zeros(1, device=dev), 1, 0)
     finally:
         mvs4net._DirectConv2d.apply = real
-    assert calls == [((8, 8, 3, 3), ("direct", "direct", "direct")), ((16, 8, 3, 3), ("mfma", "mfma", "mfma")),
+    assert calls == [((8, 8, 3, 3), ("direct", "direct", "mfma")), ((16, 8, 3, 3), ("mfma", "mfma", "mfma")),
                      ((1, 8, 1, 1), ("direct", "direct", "direct"))]
 
 
 def test_mixed_backward_routing_matches_torch():
-    """The policy's mixes through _conv2d: 64 -> 8 (FPN out4, all direct) and 16 -> 32 stride 2 (reg2d conv3: matrix-core
+    """The policy's mixes through _conv2d: 64 -> 8 (FPN out4: direct forward and input gradient, packed-tap matrix-core weight gradient) and 16 -> 32 stride 2 (reg2d conv3: matrix-core
     forward, transposed-kernel input gradient, weight gradient) -- still the right numbers."""
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5)

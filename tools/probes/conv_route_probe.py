@@ -18,7 +18,7 @@ args = ap.parse_args()
 dev = torch.device("cuda:0")
 H, W, V = 1152, 1600, args.views
 layers = [  # name, N, Cin, Cout, k, stride, h, w (input size)
-    ("fpn conv0.1 8->8", V, 8, 8, 3, 1, H, W), ("fpn conv1.0 8->16 5x5s2", V, 8, 16, 5, 2, H, W),
+    ("fpn conv0.0 3->8", V, 3, 8, 3, 1, H, W), ("fpn conv0.1 8->8", V, 8, 8, 3, 1, H, W), ("reg s4 conv0 4->8", 4, 4, 8, 3, 1, H, W), ("fpn conv1.0 8->16 5x5s2", V, 8, 16, 5, 2, H, W),
     ("fpn conv1.x 16->16", V, 16, 16, 3, 1, H // 2, W // 2), ("fpn conv2.0 16->32 5x5s2", V, 16, 32, 5, 2, H // 2, W // 2),
     ("fpn conv2.x 32->32", V, 32, 32, 3, 1, H // 4, W // 4), ("fpn conv3.0 32->64 5x5s2", V, 32, 64, 5, 2, H // 4, W // 4),
     ("fpn conv3.x 64->64", V, 64, 64, 3, 1, H // 8, W // 8), ("fpn out1 64->64 1x1", V, 64, 64, 1, 1, H // 8, W // 8),
