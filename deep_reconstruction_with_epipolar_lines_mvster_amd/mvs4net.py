@@ -540,7 +540,8 @@ class reg2d(nn.Module):
         """Same network, same parameters, with the D depth slices stacked into the batch: every layer is a 2-D
         convolution on [B*D, C, H, W]."""
         B, C, D, H, W = x.shape
-        x2d = x.permute(0, 2, 1, 3, 4).reshape(B * D, C, H, W)
+        # .contiguous(): with B = 1 the reshape is a strided VIEW, which would send conv0 down the generic F.conv2d path
+        x2d = x.permute(0, 2, 1, 3, 4).reshape(B * D, C, H, W).contiguous()
         e0 = self.conv0.forward_slices(x2d, B, D)
         e1 = self.conv2.forward_slices(self.conv1.forward_slices(e0, B, D), B, D)
         e2 = self.conv4.forward_slices(self.conv3.forward_slices(e1, B, D), B, D)
