@@ -632,7 +632,10 @@ static int wgrad_cib(int Cin, int K) {
     return K == 5 && cib == 32 ? 16 : cib;                         // 5 x 5 columns of 32 channels: 400 accumulator registers
 }
 
-constexpr int kWgMaxGroupsGrid = 512;                              // persistent workgroups over all (co, ci) blocks together
+// persistent workgroups over all (co, ci) block groups together.  The 32-channel-block kernels hold > 256 registers: one
+// workgroup per CU is resident, a second round would only add partial sums and a tail (32->32: 0.18 -> 0.16 ms with 256);
+// the others fit twice (8->8: 0.43 ms with 512, 0.50 with 256)
+constexpr int kWgGridOnePerCu = 256, kWgGridTwoPerCu = 512;
 
 struct WgPlan {
     int cib, th, ci_blocks, co_blocks, groups, nbn, E, grid_x, tiles_x, tiles_y, ntiles;
@@ -652,7 +655,7 @@ static WgPlan wgrad_plan(int N, int Cin, int Cout, int Ho, int Wo, int K, int st
     pl.tiles_x = (Wo + kMfTileW - 1) / kMfTileW;
     pl.tiles_y = (Ho + pl.th - 1) / pl.th;
     pl.ntiles = N * pl.tiles_x * pl.tiles_y;
-    int gx = kWgMaxGroupsGrid / pl.groups;
+    int gx = (pl.cib == 32 && !pl.packed ? kWgGridOnePerCu : kWgGridTwoPerCu) / pl.groups;
     if (gx < 1) gx = 1;
     pl.grid_x = pl.ntiles < gx ? pl.ntiles : gx;
     return pl;

@@ -14,7 +14,6 @@
 namespace mvster {
 
 constexpr int kMaxTop = 64;       // output channels (8 * base_channels)
-constexpr int kMaxSkip = 32;      // lateral input channels
 
 // PyTorch's align_corners=True source index: src = dst * (in - 1) / (out - 1) in float; i0 = (int)src,
 // i1 = i0 + (i0 < in - 1), lambda1 = src - i0, lambda0 = 1 - lambda1   (aten/src/ATen/native/UpSample.h)
@@ -144,31 +143,34 @@ fpn_merge_bwd_weight_kernel(const float* __restrict__ dy, const float* __restric
 
 // dfeat = transpose of the bilinear x2 upsample applied to dy, as a GATHER (ATen scatters with atomics): a low-resolution
 // pixel (i,j) collects from the <= 6 x 6 high-resolution pixels whose source footprint can contain it, with exactly the
-// forward's weights.  A workgroup owns a 32 x 8 tile of low-resolution pixels of one plane and first stages the 68 x 20
-// high-resolution pixels they can touch in LDS with coalesced row loads (every dy element is read ~1.2 times; gathering
-// straight from memory -- lanes two pixels apart, six rows each -- ran at ~1 TB/s: 0.45 ms for the 472 MB of the top level).
+// forward's weights.  A workgroup owns a 32 x 8 tile of low-resolution pixels and walks kUpPlanes planes of it: per plane
+// it stages the 68 x 20 high-resolution pixels the tile can touch in LDS with coalesced row loads (every dy element is read
+// ~1.2 times; gathering straight from memory -- lanes two pixels apart, six rows each -- ran at ~1 TB/s), the next plane's
+// window already in flight in registers while this one is reduced; the 6 + 6 interpolation weights are per lane, not per plane.
 constexpr int kUpTw = 32, kUpTh = 8;                                   // low-resolution tile
 constexpr int kUpW = 2 * kUpTw + 4, kUpH = 2 * kUpTh + 4;              // staged high-resolution window (2i-2 .. 2i+3)
+constexpr int kUpPlanes = 8;                                           // planes per workgroup
+constexpr int kUpLoads = (kUpH * kUpW + kBlock - 1) / kBlock;          // window elements per lane
 
 __global__ void __launch_bounds__(kBlock)
-fpn_upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dfeat, MergeDims dm) {
+fpn_upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dfeat, MergeDims dm, int planes) {
     __shared__ float win[kUpH][kUpW + 1];
-    const int plane = blockIdx.y;                       // n * Ct + c
     const int hw = dm.h * dm.w, HW = dm.H * dm.W;
     const int tiles_x = (dm.w + kUpTw - 1) / kUpTw;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int i0 = ty * kUpTh, j0 = tx * kUpTw;
     const int Y0 = 2 * i0 - 2, X0 = 2 * j0 - 2;
-    const float* __restrict__ d = dy + (size_t)plane * HW;
-    for (int e = threadIdx.x; e < kUpH * kUpW; e += kBlock) {
+    int woff[kUpLoads], loff[kUpLoads];                            // the lane's window elements: offset in the plane (-1: outside), slot in LDS
+#pragma unroll
+    for (int k = 0; k < kUpLoads; ++k) {
+        const int e = threadIdx.x + kBlock * k;
         const int r = e / kUpW, c = e - r * kUpW;
         const int yy = Y0 + r, xx = X0 + c;
-        win[r][c] = yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W ? d[(size_t)yy * dm.W + xx] : 0.0f;
+        loff[k] = e < kUpH * kUpW ? r * (kUpW + 1) + c : -1;
+        woff[k] = e < kUpH * kUpW && yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W ? yy * dm.W + xx : -1;
     }
-    __syncthreads();
     const int li = threadIdx.x / kUpTw, lj = threadIdx.x - li * kUpTw;
     const int i = i0 + li, j = j0 + lj;
-    if (i >= dm.h || j >= dm.w) return;
     float wy[6], wx[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -184,15 +186,33 @@ fpn_upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dfeat,
             wx[k] = (l.i0 == j ? l.l0 : 0.0f) + (l.i1 == j ? l.l1 : 0.0f);
         }
     }
-    float acc = 0.0f;
+    const int p0 = blockIdx.y * kUpPlanes, p1 = min(p0 + kUpPlanes, planes);
+    float v[kUpLoads];
+    auto fetch = [&](int plane) {
+        const float* __restrict__ d = dy + (size_t)plane * HW;
 #pragma unroll
-    for (int ky = 0; ky < 6; ++ky) {
-        float r = 0.0f;
+        for (int k = 0; k < kUpLoads; ++k) v[k] = woff[k] >= 0 ? d[woff[k]] : 0.0f;
+    };
+    fetch(p0);
+    for (int plane = p0; plane < p1; ++plane) {
+        if (plane > p0) __syncthreads();                           // the previous plane's window has been consumed
 #pragma unroll
-        for (int kx = 0; kx < 6; ++kx) r = fmaf(wx[kx], win[2 * li + ky][2 * lj + kx], r);
-        acc = fmaf(wy[ky], r, acc);
+        for (int k = 0; k < kUpLoads; ++k)
+            if (loff[k] >= 0) (&win[0][0])[loff[k]] = v[k];
+        __syncthreads();
+        if (plane + 1 < p1) fetch(plane + 1);
+        if (i < dm.h && j < dm.w) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 6; ++ky) {
+                float r = 0.0f;
+#pragma unroll
+                for (int kx = 0; kx < 6; ++kx) r = fmaf(wx[kx], win[2 * li + ky][2 * lj + kx], r);
+                acc = fmaf(wy[ky], r, acc);
+            }
+            dfeat[(size_t)plane * hw + (size_t)i * dm.w + j] = acc;
+        }
     }
-    dfeat[(size_t)plane * hw + (size_t)i * dm.w + j] = acc;
 }
 
 static int check_merge(int N, int Ct, int Cs, int h, int w, MergeDims* dm) {
@@ -250,7 +270,8 @@ extern "C" int mvster_fpn_merge_bwd(const float* dy, const float* skip, const fl
     MVSTER_BY_SKIP(fpn_merge_bwd_weight_kernel, wgrid, dy, skip, dweight, dbias, dm)
     if (int rc = launch_status()) return rc;
     static_assert(kUpTw * kUpTh == kBlock, "one lane per low-resolution pixel of the tile");
-    hipLaunchKernelGGL(fpn_upsample_bwd_kernel, dim3(((w + kUpTw - 1) / kUpTw) * ((h + kUpTh - 1) / kUpTh), N * Ct),
-                       dim3(kBlock), 0, st, dy, dfeat, dm);
+    hipLaunchKernelGGL(fpn_upsample_bwd_kernel,
+                       dim3(((w + kUpTw - 1) / kUpTw) * ((h + kUpTh - 1) / kUpTh), (N * Ct + kUpPlanes - 1) / kUpPlanes),
+                       dim3(kBlock), 0, st, dy, dfeat, dm, N * Ct);
     return launch_status();
 }
