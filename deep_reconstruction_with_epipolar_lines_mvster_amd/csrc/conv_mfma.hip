@@ -601,8 +601,18 @@ conv_mfma_wgrad_finish_kernel(const float* __restrict__ partials, float* __restr
     const int grp = blockIdx.y;
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     float s = 0.0f;
-    if (e < E)
-        for (int q = slice; q < nparts; q += 4) s += partials[((size_t)grp * nparts + q) * E + e];
+    if (e < E) {
+        // eight loads in flight per lane (one dependent load per iteration made this kernel ~25 us whatever the layer);
+        // the order of the additions is fixed, so the result stays bitwise reproducible
+        const float* __restrict__ src = partials + (size_t)grp * nparts * E + e;
+        float part[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        int q = slice;
+        for (; q + 28 < nparts; q += 32)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[u] += src[(size_t)(q + 4 * u) * E];
+        for (; q < nparts; q += 4) part[0] += src[(size_t)q * E];
+        s = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (slice != 0 || e >= E) return;
