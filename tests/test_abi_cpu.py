@@ -158,3 +158,42 @@ def test_header_is_plain_c_and_library_links_from_c(lib, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, env=env)
     assert r.returncode == 0, "abi_smoke exited %d: %s %s" % (r.returncode, r.stdout, r.stderr)
     assert "mvster C ABI v%d ok" % _lib.ABI_VERSION in r.stdout
+
+
+def test_convolution_support_and_workspace_queries(lib):
+    """Host-side queries of the matrix-core convolutions (no launch): supported (K, stride) pairs, packed-weight and
+    partial-sum workspace sizes, argument checks before any launch."""
+    import ctypes
+    ok = lib.mvster_conv_mfma_supported
+    assert [ok(32, 32, k, s) for k, s in ((1, 1), (3, 1), (3, 2), (5, 2))] == [1, 1, 1, 1]
+    assert [ok(32, 32, k, s) for k, s in ((5, 1), (1, 2), (7, 1), (3, 3))] == [0, 0, 0, 0]
+    assert ok(0, 32, 3, 1) == 0 and ok(32, 0, 3, 1) == 0
+    ws = lib.mvster_conv_mfma_workspace
+    # forward: weights re-packed to [Cin padded to 8 (stride 1) / 4 (stride 2)][K*K][Cout padded to 32]
+    assert ws(1, 20, 40, 64, 64, 3, 1, 0) == 24 * 9 * 64
+    assert ws(1, 8, 16, 64, 64, 5, 2, 0) == 8 * 25 * 32
+    # weight gradient: per-workgroup partial sums, more for more (co, ci) block groups but never zero for a supported layer
+    small, big = ws(1, 32, 32, 64, 64, 3, 1, 1), ws(5, 64, 64, 288, 400, 3, 1, 1)
+    assert 0 < small <= big
+    assert ws(5, 64, 8, 1152, 1600, 3, 1, 1) > 0                       # packed-tap kernel (<= 8 output channels)
+    assert ws(1, 32, 32, 64, 64, 7, 1, 0) == 0 and ws(0, 32, 32, 64, 64, 3, 1, 0) == 0
+    null = ctypes.c_void_p(None)
+    assert lib.mvster_conv_mfma_fwd(null, null, null, null, null, 0, 1, 32, 32, 8, 8, 3, 1, 0, null) != 0
+    assert lib.mvster_conv_mfma_wgrad(null, null, null, null, 0, 1, 32, 32, 8, 8, 3, 1, null) != 0
+    assert lib.mvster_conv_mfma_transposed(null, null, null, null, 0, 1, 32, 32, 8, 8, 16, 16, 3, null) != 0
+
+
+def test_convolution_routing_policy_is_pure_host_logic():
+    """mvs4net._conv_route needs the library (support queries) but no GPU: the policy table the docs quote."""
+    from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net
+    r = mvs4net._conv_route
+    assert r(3, 8, 3, 1) == ("direct", "direct", "mfma") and r(8, 1, 1, 1) == ("direct", "direct", "direct")
+    assert r(64, 64, 3, 1) == ("mfma", "mfma", "mfma") and r(16, 32, 5, 2) == ("mfma", "mfma", "mfma")
+    assert r(192, 64, 3, 1) == ("mfma", "mfma", "miopen") and r(8, 8, 5, 1) is None
+    try:
+        mvs4net._MFMA_CONV = False
+        assert r(64, 64, 3, 1) is None and r(8, 8, 3, 1) == ("direct", "direct", "direct")
+        mvs4net._DIRECT_CONV = False
+        assert r(8, 8, 3, 1) is None
+    finally:
+        mvs4net._MFMA_CONV = mvs4net._DIRECT_CONV = True
