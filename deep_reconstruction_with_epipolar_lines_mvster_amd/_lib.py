@@ -58,6 +58,8 @@ PROTOTYPES = {
     "mvster_conv_mfma_workspace": [_i, _i, _i, _i, _i, _i, _i, _i],
     "mvster_conv_mfma_fwd": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_conv_mfma_wgrad": [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvster_conv_mfma_depth3_fwd": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvster_conv_mfma_depth3_wgrad": [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_conv_mfma_transposed": [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_conv_direct_supported": [_i, _i, _i],
     "mvster_conv_direct_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -34,13 +34,29 @@ struct MfDims {
     int N, Cin, Cout, H, W, Ho, Wo;   // x [N,Cin,H,W] -> y [N,Cout,Ho,Wo]
     int CinPad, CoutPad;              // packed weights [CinPad][K*K][CoutPad]
     int tiles_x, tiles_y;
+    int depth, Creal;                 // depth > 0: the Cin = 3 * Creal input channels are VIRTUAL, see input_plane()
 };
+
+// (3,3,3) layers over depth slices stacked into the batch (sample n = b * depth + d): input channel cv = dz * Creal + c of
+// sample n is channel c of sample n + dz - 1, zero where d + dz - 1 leaves [0, depth) -- the three depth-shifted copies the
+// reference's Conv3d sees, read in place instead of from a concatenated tensor.  -> plane pointer, or nullptr for "zero".
+__device__ __forceinline__ const float* input_plane(const float* __restrict__ x, int n, int cv, int Cin, int depth, int Creal,
+                                                     int HW) {
+    if (cv >= Cin) return nullptr;
+    if (depth <= 0) return x + ((size_t)n * Cin + cv) * HW;
+    const int dz = cv / Creal, c = cv - dz * Creal;
+    const int dd = n % depth + dz - 1;
+    return dd >= 0 && dd < depth ? x + ((size_t)(n + dz - 1) * Creal + c) * HW : nullptr;
+}
 
 __host__ __device__ constexpr int round_to_residue(int v, int mod, int res) { return v + ((res - v % mod) + mod) % mod; }
 
 // wp[ci][tap][co], zero-padded.  mode 0: w is [Cout][Cin][KK] (a layer's own weights, forward).  mode 1: w is
 // [Cin][Cout][KK] and the taps are mirrored (the input gradient of a stride-1 layer is the convolution of dy with these).
 // mode 2: w is [Cin][Cout][KK], taps as they are (transposed convolution).
+// mode 3: input gradient of a depth-stacked (3,3,3) layer: w is [Cin/3][3*Cout][KK] (the layer's folded weights, Cin/3 = its
+//         output channels, Cout = its real input channels); virtual input channel cv = dz' * (Cin/3) + co reads dy of slice
+//         n + dz' - 1, which saw this slice under depth tap 2 - dz': wp[cv][tap][c] = w[co][(2 - dz') * Cout + c][KK-1-tap].
 __global__ void __launch_bounds__(kBlock)
 conv_mfma_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int KK, int CinPad, int CoutPad,
                       int mode) {
@@ -48,8 +64,14 @@ conv_mfma_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int C
     if (e >= CinPad * KK * CoutPad) return;
     const int co = e % CoutPad, tap = (e / CoutPad) % KK, ci = e / (CoutPad * KK);
     float v = 0.0f;
-    if (ci < Cin && co < Cout)
-        v = mode == 0 ? w[((size_t)co * Cin + ci) * KK + tap] : w[((size_t)ci * Cout + co) * KK + (mode == 1 ? KK - 1 - tap : tap)];
+    if (ci < Cin && co < Cout) {
+        if (mode == 3) {
+            const int cl = Cin / 3, dz = ci / cl, col = ci - dz * cl;
+            v = w[((size_t)col * 3 * Cout + (2 - dz) * Cout + co) * KK + (KK - 1 - tap)];
+        } else {
+            v = mode == 0 ? w[((size_t)co * Cin + ci) * KK + tap] : w[((size_t)ci * Cout + co) * KK + (mode == 1 ? KK - 1 - tap : tap)];
+        }
+    }
     wp[e] = v;
 }
 
@@ -85,7 +107,6 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
     const int co0 = blockIdx.y * COW;
     const int gy0 = ty * kMfRowsFwd * S - P, gx0 = tx * kMfTileW * S - P;
     const int HW = d.H * d.W;
-    const float* __restrict__ xn = x + (size_t)n * d.Cin * HW;
 
     // this lane's elements of an input plane: the same window positions for every plane of every chunk
     int goff[NI];                                                  // offset inside the plane, -1: outside the image / the window
@@ -110,10 +131,9 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
     auto fetch = [&](int ci0) {                                    // global -> registers: in flight while the MFMAs of the previous chunk run
 #pragma unroll
         for (int pp = 0; pp < PPW; ++pp) {
-            const int ci = ci0 + wave * PPW + pp;
-            const float* __restrict__ plane = xn + (size_t)ci * HW;
+            const float* __restrict__ plane = input_plane(x, n, ci0 + wave * PPW + pp, d.Cin, d.depth, d.Creal, HW);
 #pragma unroll
-            for (int k = 0; k < NI; ++k) vin[pp][k] = ci < d.Cin && goff[k] >= 0 ? plane[goff[k]] : 0.0f;
+            for (int k = 0; k < NI; ++k) vin[pp][k] = plane != nullptr && goff[k] >= 0 ? plane[goff[k]] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
@@ -319,6 +339,7 @@ struct MfWgDims {
     int N, Cin, Cout, H, W, Ho, Wo;
     int tiles_x, tiles_y, ntiles;
     int ci_blocks;                    // blockIdx.y = co_block * ci_blocks + ci_block
+    int depth, Creal;                 // depth > 0: virtual input channels, see input_plane()
 };
 
 template <int KS, int S, int CIB, int TH>
@@ -382,10 +403,9 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
         }
 #pragma unroll
         for (int pp = 0; pp < PPW; ++pp) {
-            const int ci = ci0 + wave * PPW + pp;
-            const float* __restrict__ plane = x + ((size_t)n * d.Cin + ci) * HW;
+            const float* __restrict__ plane = input_plane(x, n, ci0 + wave * PPW + pp, d.Cin, d.depth, d.Creal, HW);
 #pragma unroll
-            for (int k = 0; k < NI; ++k) vx[pp][k] = ci < d.Cin && goff[k] >= 0 ? plane[goff[k]] : 0.0f;
+            for (int k = 0; k < NI; ++k) vx[pp][k] = plane != nullptr && goff[k] >= 0 ? plane[goff[k]] : 0.0f;
         }
         int doff[ND];
 #pragma unroll
@@ -693,18 +713,19 @@ extern "C" long long mvster_conv_mfma_workspace(int N, int Cin, int Cout, int H,
 #define MVSTER_MFMA_FWD(KS_, S_, NB_, CB_) \
     hipLaunchKernelGGL((conv_mfma_fwd_kernel<KS_, S_, NB_, CB_>), grid, dim3(kBlock), 0, st, x, workspace, bias, y, d)
 
-extern "C" int mvster_conv_mfma_fwd(const float* x, const float* weight, const float* bias, float* y, float* workspace,
-                                    long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride,
-                                    int flip, mvster_stream_t stream) {
+// pack_mode: see conv_mfma_pack_kernel; depth > 0: Cin = 3 * Creal virtual input channels over depth-shifted samples
+static int conv_mfma_fwd_impl(const float* x, const float* weight, const float* bias, float* y, float* workspace,
+                              long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride,
+                              int pack_mode, int depth, int Creal, mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(weight); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(workspace);
     MVSTER_REQUIRE_SHAPE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (long long)H * W <= kMaxPlane);
     if (!mvster_conv_mfma_supported(Cin, Cout, K, stride)) return MVSTER_ERR_UNSUPPORTED;
-    MVSTER_REQUIRE_SHAPE(!flip || stride == 1);
+    MVSTER_REQUIRE_SHAPE(pack_mode == 0 || stride == 1);
     MVSTER_REQUIRE_SHAPE(workspace_floats >= mvster_conv_mfma_workspace(N, Cin, Cout, H, W, K, stride, MVSTER_CONV_OP_FWD));
     const int P = K / 2, cb = stride == 1 ? 8 : 4;
     MfDims d;
-    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W;
+    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.depth = depth; d.Creal = Creal;
     d.Ho = (H + 2 * P - K) / stride + 1;
     d.Wo = (W + 2 * P - K) / stride + 1;
     d.CinPad = (Cin + cb - 1) / cb * cb;
@@ -716,7 +737,7 @@ extern "C" int mvster_conv_mfma_fwd(const float* x, const float* weight, const f
     const hipStream_t st = as_stream(stream);
     const int packed = d.CinPad * K * K * d.CoutPad;
     hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
-                       K * K, d.CinPad, d.CoutPad, flip ? 1 : 0);
+                       K * K, d.CinPad, d.CoutPad, pack_mode);
     const bool two = d.CoutPad % 64 == 0;                          // 64 output channels per workgroup when they divide
     const dim3 grid((unsigned)tiles, d.CoutPad / (two ? 64 : 32));
     if (K == 1) { if (two) MVSTER_MFMA_FWD(1, 1, 2, 8); else MVSTER_MFMA_FWD(1, 1, 1, 8); }
@@ -724,6 +745,23 @@ extern "C" int mvster_conv_mfma_fwd(const float* x, const float* weight, const f
     else if (K == 3) { if (two) MVSTER_MFMA_FWD(3, 2, 2, 4); else MVSTER_MFMA_FWD(3, 2, 1, 4); }
     else { if (two) MVSTER_MFMA_FWD(5, 2, 2, 4); else MVSTER_MFMA_FWD(5, 2, 1, 4); }
     return launch_status();
+}
+
+extern "C" int mvster_conv_mfma_fwd(const float* x, const float* weight, const float* bias, float* y, float* workspace,
+                                    long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride,
+                                    int flip, mvster_stream_t stream) {
+    return conv_mfma_fwd_impl(x, weight, bias, y, workspace, workspace_floats, N, Cin, Cout, H, W, K, stride, flip ? 1 : 0, 0, 0,
+                              stream);
+}
+
+extern "C" int mvster_conv_mfma_depth3_fwd(const float* x, const float* weight, const float* bias, float* y, float* workspace,
+                                           long long workspace_floats, int N, int C, int Cout, int H, int W, int K, int depth,
+                                           int input_gradient, mvster_stream_t stream) {
+    MVSTER_REQUIRE_SHAPE(depth > 0 && N > 0 && N % depth == 0 && C > 0 && Cout > 0 && (K == 1 || K == 3));
+    // forward: 3*C virtual channels of x -> Cout.  Input gradient: x := dy [N,Cout,..], 3*Cout virtual channels -> C.
+    if (input_gradient)
+        return conv_mfma_fwd_impl(x, weight, nullptr, y, workspace, workspace_floats, N, 3 * Cout, C, H, W, K, 1, 3, depth, Cout, stream);
+    return conv_mfma_fwd_impl(x, weight, bias, y, workspace, workspace_floats, N, 3 * C, Cout, H, W, K, 1, 0, depth, C, stream);
 }
 
 #define MVSTER_MFMA_TR(KS_, NB_, CB_) \
@@ -741,7 +779,7 @@ extern "C" int mvster_conv_mfma_transposed(const float* x, const float* weight, 
     MVSTER_REQUIRE_SHAPE((Ho + 2 * P - K) / 2 + 1 == H && (Wo + 2 * P - K) / 2 + 1 == W);
     const int cb = K == 3 ? 8 : 4;
     MfDims d;
-    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.Ho = Ho; d.Wo = Wo;
+    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.Ho = Ho; d.Wo = Wo; d.depth = 0; d.Creal = 0;
     d.CinPad = (Cin + cb - 1) / cb * cb;
     d.CoutPad = (Cout + 31) / 32 * 32;
     const long long packed = (long long)d.CinPad * K * K * d.CoutPad;
@@ -790,9 +828,9 @@ extern "C" int mvster_conv_mfma_transposed(const float* x, const float* weight, 
         default: MVSTER_MFMA_WG(KS_, S_, 32, TH_) break;    \
     }
 
-extern "C" int mvster_conv_mfma_wgrad(const float* x, const float* dy, float* dweight, float* workspace,
-                                      long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride,
-                                      mvster_stream_t stream) {
+static int conv_mfma_wgrad_impl(const float* x, const float* dy, float* dweight, float* workspace, long long workspace_floats,
+                                int N, int Cin, int Cout, int H, int W, int K, int stride, int depth, int Creal,
+                                mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(dy); MVSTER_REQUIRE_PTR(dweight); MVSTER_REQUIRE_PTR(workspace);
     MVSTER_REQUIRE_SHAPE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (long long)H * W <= kMaxPlane);
@@ -800,7 +838,7 @@ extern "C" int mvster_conv_mfma_wgrad(const float* x, const float* dy, float* dw
     MVSTER_REQUIRE_SHAPE(workspace_floats >= mvster_conv_mfma_workspace(N, Cin, Cout, H, W, K, stride, MVSTER_CONV_OP_WGRAD));
     const int P = K / 2;
     MfWgDims d;
-    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W;
+    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.depth = depth; d.Creal = Creal;
     d.Ho = (H + 2 * P - K) / stride + 1;
     d.Wo = (W + 2 * P - K) / stride + 1;
     const WgPlan pl = wgrad_plan(N, Cin, Cout, d.Ho, d.Wo, K, stride);
@@ -824,4 +862,18 @@ extern "C" int mvster_conv_mfma_wgrad(const float* x, const float* dy, float* dw
     hipLaunchKernelGGL(conv_mfma_wgrad_finish_kernel, dim3(grid_for(pl.E, 64), pl.groups), dim3(kBlock), 0, st, workspace, dweight,
                        pl.grid_x, pl.E, pl.nbn, K, pl.cib, Cin, Cout, pl.ci_blocks, pl.packed ? 1 : 0);
     return launch_status();
+}
+
+extern "C" int mvster_conv_mfma_wgrad(const float* x, const float* dy, float* dweight, float* workspace,
+                                      long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride,
+                                      mvster_stream_t stream) {
+    return conv_mfma_wgrad_impl(x, dy, dweight, workspace, workspace_floats, N, Cin, Cout, H, W, K, stride, 0, 0, stream);
+}
+
+extern "C" int mvster_conv_mfma_depth3_wgrad(const float* x, const float* dy, float* dweight, float* workspace,
+                                             long long workspace_floats, int N, int C, int Cout, int H, int W, int K, int depth,
+                                             mvster_stream_t stream) {
+    MVSTER_REQUIRE_SHAPE(depth > 0 && N > 0 && N % depth == 0 && C > 0 && Cout > 0 && (K == 1 || K == 3));
+    if (K == 3 && Cout <= 8) return MVSTER_ERR_UNSUPPORTED;       // the packed-tap kernel reads real planes only
+    return conv_mfma_wgrad_impl(x, dy, dweight, workspace, workspace_floats, N, 3 * C, Cout, H, W, K, 1, depth, C, stream);
 }

@@ -139,7 +139,9 @@ def _conv3d_as_2d(conv, x2d, B, D):
     """A Conv3d whose kernel is (1,k,k) or (3,k,k) with unit depth stride, evaluated as ONE conv2d on depth slices
     stacked into the batch dimension, x2d = [B*D, Cin, H, W].  (3,k,k): the three depth-shifted copies of the input are
     concatenated along channels and the weight is folded to [Cout, 3*Cin, k, k].  MIOpen's conv3d weight-gradient path
-    for these shapes is a naive kernel (79 ms per layer at DTU resolution); its 2-D paths are Winograd/implicit GEMM."""
+    for these shapes is a naive kernel (79 ms per layer at DTU resolution); its 2-D paths are Winograd/implicit GEMM.
+    On the matrix-core kernels the concatenation is virtual (``_MfmaDepthConv``: the three depth-shifted planes are read in
+    place, forward and both gradients), which removes the copies and their backward."""
     w = conv.weight
     kd = w.shape[2]
     stride, pad = conv.stride[1:], conv.padding[1:]
@@ -147,10 +149,15 @@ def _conv3d_as_2d(conv, x2d, B, D):
         return _conv2d(x2d, w[:, :, 0], conv.bias, stride, pad)
     assert kd == 3 and conv.stride[0] == 1 and conv.padding[0] == 1
     C, H, W = x2d.shape[1:]
+    w2 = w.permute(0, 2, 1, 3, 4).reshape(w.shape[0], 3 * w.shape[1], w.shape[3], w.shape[4])
+    k = w.shape[3]
+    if (_MFMA_CONV and _DEPTH_IN_PLACE and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.is_contiguous() and conv.bias is None
+            and w.shape[3] == w.shape[4] and k in (1, 3) and tuple(stride) == (1, 1) and tuple(pad) == (k // 2, k // 2)
+            and w.shape[0] >= 16 and 3 * C <= _MFMA_MAX_WGRAD_CIN):
+        return _MfmaDepthConv.apply(x2d, w2, D)
     x5 = x2d.view(B, D, C, H, W)
     pad_slice = x5.new_zeros(B, 1, C, H, W)
     stacked = torch.cat([torch.cat([pad_slice, x5[:, :-1]], 1), x5, torch.cat([x5[:, 1:], pad_slice], 1)], 2)
-    w2 = w.permute(0, 2, 1, 3, 4).reshape(w.shape[0], 3 * w.shape[1], w.shape[3], w.shape[4])
     return _conv2d(stacked.view(B * D, 3 * C, H, W), w2, conv.bias, stride, pad)
 
 
@@ -276,6 +283,49 @@ class _DirectConv2d(torch.autograd.Function):
         return dx, dweight, dbias, None, None
 
 
+class _MfmaDepthConv(torch.autograd.Function):
+    """A (3,k,k) Conv3d (unit strides, padding (1,k//2,k//2), no bias) on depth slices stacked into the batch,
+    x [B*D,C,H,W], weight folded to [Cout,3C,k,k]: the matrix-core kernels read the depth-shifted planes in place
+    (csrc/conv_mfma.hip ``input_plane``) -- forward, input gradient and weight gradient, no concatenated copy either way."""
+
+    @staticmethod
+    def forward(ctx, x, w2, depth):
+        N, C, H, W = x.shape
+        Cout, K = w2.shape[0], w2.shape[2]
+        dev = x.device
+        y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=dev)
+        ws, need = _mfma_workspace(_lib.load(), dev, N, 3 * C, Cout, H, W, K, 1, 0)
+        with _on(dev):
+            _lib.call("mvster_conv_mfma_depth3_fwd", x.data_ptr(), w2.data_ptr(), None, y.data_ptr(), ws.data_ptr(), need,
+                      N, C, Cout, H, W, K, depth, 0, _stream(dev))
+        ctx.save_for_backward(x, w2)
+        ctx.depth = depth
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        N, C, H, W = x.shape
+        Cout, K = w2.shape[0], w2.shape[2]
+        dy = dy.contiguous()
+        dev = x.device
+        lib = _lib.load()
+        dx = dw = None
+        with _on(dev):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                ws, need = _mfma_workspace(lib, dev, N, 3 * Cout, C, H, W, K, 1, 0)
+                _lib.call("mvster_conv_mfma_depth3_fwd", dy.data_ptr(), w2.data_ptr(), None, dx.data_ptr(), ws.data_ptr(), need,
+                          N, C, Cout, H, W, K, ctx.depth, 1, _stream(dev))
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(w2)
+                ws, need = _mfma_workspace(lib, dev, N, 3 * C, Cout, H, W, K, 1, 1)
+                _lib.call("mvster_conv_mfma_depth3_wgrad", x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), need,
+                          N, C, Cout, H, W, K, ctx.depth, _stream(dev))
+        return dx, dw, None
+
+
 class _MfmaConvTranspose2d(torch.autograd.Function):
     """conv_transpose2d(x, weight [Cin,Cout,3,3], stride 2, padding 1, output_padding 1) on the matrix cores
     (csrc/conv_mfma.hip): forward = the gather-form transposed kernel, input gradient = the stride-2 forward kernel on dy,
@@ -328,6 +378,7 @@ def _conv_transpose2d_x2(x, weight):
 
 _DIRECT_CONV = True          # few-channel stride-1 layers through csrc/conv_direct.hip; False: the other two
 _MFMA_CONV = True            # many-channel layers through csrc/conv_mfma.hip; False: MIOpen
+_DEPTH_IN_PLACE = True       # (3,k,k) layers read their depth-shifted planes in place (needs _MFMA_CONV); False: concatenate
 # Routing policy: every layer's three operations are routed separately on measured merit (tools/probes/conv_route_probe.py:
 # DTU resolution, the five views of FPN4 in one batch / the four depth slices of reg2d stage 4; ms direct / mfma / MIOpen):
 #   forward   8->8 0.29/0.50/0.83, 16->16 0.17/0.24/0.30, 64->8 1.55/2.75/2.97, 64->16 0.68/0.72/0.86, 48->16 0.41/0.46/0.50;

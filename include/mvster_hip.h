@@ -315,6 +315,22 @@ int mvster_conv_mfma_fwd(const float *x, const float *weight, const float *bias,
                          mvster_stream_t stream);
 int mvster_conv_mfma_wgrad(const float *x, const float *dy, float *dweight, float *workspace, long long workspace_floats,
                            int N, int Cin, int Cout, int H, int W, int K, int stride, mvster_stream_t stream);
+/* The (3,3,3) layers of reg2d (models/mvs4net_utils.py:892,895,898: Conv3d kernel 3, stride 1, padding 1) over depth slices
+ * stacked into the batch, WITHOUT materialising the three depth-shifted copies of the input: sample n = b*depth + d; input
+ * channel dz*C + c of sample n is channel c of sample n + dz - 1, zero where d + dz - 1 leaves [0, depth).
+ *   x [N,C,H,W] (N % depth == 0), weight [Cout, 3*C, K, K] (the Conv3d weight [Cout,C,3,K,K] with the depth taps folded
+ *   into the channel axis, depth tap major), y, dy [N,Cout,H,W], stride 1, padding K/2.
+ *   _fwd, input_gradient = 0 : y = conv(x, weight) (+ bias)
+ *   _fwd, input_gradient = 1 : pass x := dy, y := dx [N,C,H,W]: the layer's input gradient (bias ignored)
+ *   _wgrad                   : dweight [Cout, 3*C, K, K]
+ *   workspace: mvster_conv_mfma_workspace(N, 3*C, Cout, ...) (forward, weight gradient) / (N, 3*Cout, C, ...) (input gradient).
+ *   3x3 layers with <= 8 output channels: _wgrad returns MVSTER_ERR_UNSUPPORTED. */
+int mvster_conv_mfma_depth3_fwd(const float *x, const float *weight, const float *bias, float *y, float *workspace,
+                                long long workspace_floats, int N, int C, int Cout, int H, int W, int K, int depth,
+                                int input_gradient, mvster_stream_t stream);
+int mvster_conv_mfma_depth3_wgrad(const float *x, const float *dy, float *dweight, float *workspace,
+                                  long long workspace_floats, int N, int C, int Cout, int H, int W, int K, int depth,
+                                  mvster_stream_t stream);
 /* Transposed convolution, stride 2, K in {3, 5}, padding K/2, as a gather (no zero insertion):
  *   y[co][oy][ox] = sum_{ci, taps of matching parity} weight[ci][co][ky][kx] * x[ci][(oy + K/2 - ky)/2][(ox + K/2 - kx)/2]
  * replaces: reg2d's nn.ConvTranspose3d (1,3,3) up-convolutions (models/mvs4net_utils.py:901-912, as conv_transpose2d over

@@ -178,3 +178,37 @@ def test_whole_networks_on_hip_convolutions_match_the_miopen_route(which):
           % (which, off, med, rel[worst], worst))
     assert off < 2e-3
     assert med < 1e-3 and rel[worst] < 5e-2
+
+
+@pytest.mark.parametrize("B,D,C,Cout,H,W", [(1, 4, 16, 16, 24, 40), (2, 8, 32, 32, 9, 35), (1, 3, 8, 16, 17, 33), (2, 1, 16, 32, 8, 32)])
+def test_depth_taps_read_in_place_match_conv3d(B, D, C, Cout, H, W):
+    """reg2d's (3,3,3) layers (models/mvs4net_utils.py:892,895,898) on depth slices stacked into the batch, the three
+    depth-shifted copies read in place: forward, input gradient, weight gradient vs F.conv3d in float64 (first / last
+    slice of every batch item see zeros beyond the volume; D = 1: both neighbours are zeros)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + D + C + Cout + H)
+    x = torch.randn(B, C, D, H, W, generator=g)
+    w = torch.randn(Cout, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, 1, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy.double()).sum().backward()
+
+    conv = torch.nn.Conv3d(C, Cout, 3, 1, 1, bias=False).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    x2d = x.permute(0, 2, 1, 3, 4).reshape(B * D, C, H, W).contiguous().to(dev).requires_grad_(True)
+    calls = []
+    real_call = mvs4net._lib.call
+    mvs4net._lib.call = lambda name, *a: (calls.append(name), real_call(name, *a))[1]
+    try:
+        y2d = mvs4net._conv3d_as_2d(conv, x2d, B, D)
+        (y2d * gy.permute(0, 2, 1, 3, 4).reshape(B * D, Cout, H, W).to(dev)).sum().backward()
+    finally:
+        mvs4net._lib.call = real_call
+    assert calls == ["mvster_conv_mfma_depth3_fwd", "mvster_conv_mfma_depth3_fwd", "mvster_conv_mfma_depth3_wgrad"]
+    tag = "(3,3,3) %d->%d B%d D%d %dx%d" % (C, Cout, B, D, H, W)
+    back = lambda t, ch: t.view(B, D, ch, H, W).permute(0, 2, 1, 3, 4)
+    _close(back(y2d, Cout), yr, tag + " forward", 2e-6)
+    _close(back(x2d.grad, C), xr.grad, tag + " d/dx", 2e-6)
+    _close(conv.weight.grad, wr.grad, tag + " d/dweight", 1e-5)
