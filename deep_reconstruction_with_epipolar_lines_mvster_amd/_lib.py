@@ -54,6 +54,8 @@ PROTOTYPES = {
     "mvster_bn_train_bwd_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
     "mvster_fpn_merge_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_fpn_merge_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvster_fpn_head_gather_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mvster_fpn_head_gather_bwd": [_vp, _vp, _i, _i, _i, _vp],
     "mvster_conv_mfma_supported": [_i, _i, _i, _i],
     "mvster_conv_mfma_workspace": [_i, _i, _i, _i, _i, _i, _i, _i],
     "mvster_conv_mfma_fwd": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

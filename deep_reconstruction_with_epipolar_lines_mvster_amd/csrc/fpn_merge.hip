@@ -215,6 +215,144 @@ fpn_upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dfeat,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Top pyramid level without its 64-channel full-resolution map.  The reference computes
+//     intra = bilinear_x2(feat) + inner3(conv0)          [N,64,H,W]   (472 MB per view at DTU resolution)
+//     out4  = conv3x3(intra, W4)                          [N, 8,H,W]
+// (models/mvs4net_utils.py:500-505) and nothing else reads `intra`.  Both steps are linear, so the channel contraction of
+// the 3x3 layer can be done BEFORE the upsampling, at a quarter of the pixels:
+//     G[(co,tap)] = sum_c W4[co][c][tap] * (feat[c] + bias[c])      low resolution, 72 channels   (a 1x1 layer, csrc/conv_mfma.hip)
+//     out4[co](Y,X) = sum_tap [ (Y,X)+tap inside the image ] * bilinear_x2(G[(co,tap)])((Y,X)+tap)   <- this kernel
+//                   + conv3x3(conv0, W4 o W_inner3)(Y,X)                                              (an 8 -> 8 layer, `base`)
+// Same function, different association: the 64-channel full-resolution tensor and the five passes over it (merge forward,
+// three merge-backward passes, the 64 -> 8 layer's three operations) disappear, the flops drop 4x.
+// Forward: a workgroup owns a 32 x 8 output tile, stages the <= 8 x 20 low-resolution window of all 72 planes in LDS and
+// every lane interpolates its pixel's nine shifted samples of eight channels from there.
+constexpr int kHeadTaps = 9, kHeadCo = 8, kHeadPlanes = kHeadTaps * kHeadCo;
+constexpr int kHeadTw = 32, kHeadTh = 8;
+constexpr int kHeadLw = 20, kHeadLh = 8;       // low-resolution window of a tile plus its one-pixel ring: <= 19 x 7 (scale < 1/2)
+
+struct HeadDims {
+    int N, h, w, H, W;
+    float sy, sx;
+};
+
+__global__ void __launch_bounds__(kBlock)
+fpn_head_gather_fwd_kernel(const float* __restrict__ g, const float* __restrict__ base, float* __restrict__ out, HeadDims dm) {
+    __shared__ float win[kHeadPlanes][kHeadLh * kHeadLw];
+    const int n = blockIdx.y;
+    const int tiles_x = (dm.W + kHeadTw - 1) / kHeadTw;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int Y0 = ty * kHeadTh, X0 = tx * kHeadTw;
+    const int i_lo = source_index(max(Y0 - 1, 0), dm.sy, dm.h).i0, j_lo = source_index(max(X0 - 1, 0), dm.sx, dm.w).i0;
+    const int hw = dm.h * dm.w, HW = dm.H * dm.W;
+    const float* __restrict__ gn = g + (size_t)n * kHeadPlanes * hw;
+    for (int e = threadIdx.x; e < kHeadPlanes * kHeadLh * kHeadLw; e += kBlock) {
+        const int plane = e / (kHeadLh * kHeadLw), rem = e - plane * (kHeadLh * kHeadLw);
+        const int r = rem / kHeadLw, c = rem - r * kHeadLw;
+        const int i = i_lo + r, j = j_lo + c;
+        win[plane][rem] = i < dm.h && j < dm.w ? gn[(size_t)plane * hw + (size_t)i * dm.w + j] : 0.0f;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / kHeadTw, lx = threadIdx.x - ly * kHeadTw;
+    const int Y = Y0 + ly, X = X0 + lx;
+    if (Y >= dm.H || X >= dm.W) return;
+    Lerp py[3], px[3];
+    bool oky[3], okx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int yy = Y + k - 1, xx = X + k - 1;
+        oky[k] = yy >= 0 && yy < dm.H;
+        okx[k] = xx >= 0 && xx < dm.W;
+        py[k] = source_index(oky[k] ? yy : Y, dm.sy, dm.h);
+        px[k] = source_index(okx[k] ? xx : X, dm.sx, dm.w);
+        py[k].i0 -= i_lo; py[k].i1 -= i_lo;
+        px[k].i0 -= j_lo; px[k].i1 -= j_lo;
+    }
+    float acc[kHeadCo];
+    const size_t o = (size_t)n * kHeadCo * HW + (size_t)Y * dm.W + X;
+#pragma unroll
+    for (int co = 0; co < kHeadCo; ++co) acc[co] = base[o + (size_t)co * HW];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            if (!(oky[ky] && okx[kx])) continue;
+            const int o00 = py[ky].i0 * kHeadLw + px[kx].i0, o01 = py[ky].i0 * kHeadLw + px[kx].i1;
+            const int o10 = py[ky].i1 * kHeadLw + px[kx].i0, o11 = py[ky].i1 * kHeadLw + px[kx].i1;
+            const float w00 = py[ky].l0 * px[kx].l0, w01 = py[ky].l0 * px[kx].l1, w10 = py[ky].l1 * px[kx].l0, w11 = py[ky].l1 * px[kx].l1;
+#pragma unroll
+            for (int co = 0; co < kHeadCo; ++co) {
+                const float* __restrict__ p = win[co * kHeadTaps + ky * 3 + kx];
+                acc[co] += (w00 * p[o00] + w01 * p[o01]) + (w10 * p[o10] + w11 * p[o11]);
+            }
+        }
+#pragma unroll
+    for (int co = 0; co < kHeadCo; ++co) out[o + (size_t)co * HW] = acc[co];
+}
+
+// Backward of the gather w.r.t. G: dG[(co,tap)] = transposed upsample of dy[co] shifted by the tap.  Same tiling as
+// fpn_upsample_bwd_kernel (32 x 8 low-resolution pixels, the high-resolution window they can touch in LDS, one ring wider
+// for the shifts); a lane keeps its 8 x 8 window values in registers and forms the nine taps' sums from them.
+constexpr int kHeadBw = 2 * kUpTw + 6, kHeadBh = 2 * kUpTh + 6;
+
+__global__ void __launch_bounds__(kBlock)
+fpn_head_gather_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dg, HeadDims dm) {
+    __shared__ float win[kHeadBh][kHeadBw + 1];
+    const int n = blockIdx.y / kHeadCo, co = blockIdx.y - n * kHeadCo;
+    const int hw = dm.h * dm.w, HW = dm.H * dm.W;
+    const int tiles_x = (dm.w + kUpTw - 1) / kUpTw;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int i0 = ty * kUpTh, j0 = tx * kUpTw;
+    const int Y0 = 2 * i0 - 3, X0 = 2 * j0 - 3;                    // window origin: positions 2i-2 .. 2i+3, sources one further out
+    const float* __restrict__ d = dy + ((size_t)n * kHeadCo + co) * HW;
+    for (int e = threadIdx.x; e < kHeadBh * kHeadBw; e += kBlock) {
+        const int r = e / kHeadBw, c = e - r * kHeadBw;
+        const int yy = Y0 + r, xx = X0 + c;
+        win[r][c] = yy >= 0 && yy < dm.H && xx >= 0 && xx < dm.W ? d[(size_t)yy * dm.W + xx] : 0.0f;
+    }
+    __syncthreads();
+    const int li = threadIdx.x / kUpTw, lj = threadIdx.x - li * kUpTw;
+    const int i = i0 + li, j = j0 + lj;
+    if (i >= dm.h || j >= dm.w) return;
+    float wy[6], wx[6];                                            // weight of position 2i-2+k (2j-2+k) on this low-resolution pixel
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int yy = 2 * i - 2 + k, xx = 2 * j - 2 + k;
+        wy[k] = 0.0f;
+        wx[k] = 0.0f;
+        if (yy >= 0 && yy < dm.H) {
+            const Lerp l = source_index(yy, dm.sy, dm.h);
+            wy[k] = (l.i0 == i ? l.l0 : 0.0f) + (l.i1 == i ? l.l1 : 0.0f);
+        }
+        if (xx >= 0 && xx < dm.W) {
+            const Lerp l = source_index(xx, dm.sx, dm.w);
+            wx[k] = (l.i0 == j ? l.l0 : 0.0f) + (l.i1 == j ? l.l1 : 0.0f);
+        }
+    }
+    float v[8][8];                                                 // dy at rows 2i-3 .. 2i+4, columns 2j-3 .. 2j+4
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v[a][b] = win[2 * li + a][2 * lj + b];
+    float* __restrict__ o = dg + ((size_t)n * kHeadPlanes + co * kHeadTaps) * hw + (size_t)i * dm.w + j;
+#pragma unroll
+    for (int ty3 = 0; ty3 < 3; ++ty3)
+#pragma unroll
+        for (int tx3 = 0; tx3 < 3; ++tx3) {
+            // the sample at position p = (Y,X) + tap came from output pixel p - tap: rows 2i-2+ky - (ty3-1) = window row ky + 2 - ty3
+            float acc = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 6; ++ky) {
+                float r = 0.0f;
+#pragma unroll
+                for (int kx = 0; kx < 6; ++kx) r = fmaf(wx[kx], v[ky + 2 - ty3][kx + 2 - tx3], r);
+                acc = fmaf(wy[ky], r, acc);
+            }
+            o[(size_t)(ty3 * 3 + tx3) * hw] = acc;
+        }
+}
+
 static int check_merge(int N, int Ct, int Cs, int h, int w, MergeDims* dm) {
     MVSTER_REQUIRE_SHAPE(N > 0 && N <= 65535 && Ct > 0 && Cs > 0 && h > 1 && w > 1);
     MVSTER_REQUIRE_SHAPE((long long)4 * h * w <= kMaxPlane && (long long)N * Ct <= 65535);
@@ -273,5 +411,26 @@ extern "C" int mvster_fpn_merge_bwd(const float* dy, const float* skip, const fl
     hipLaunchKernelGGL(fpn_upsample_bwd_kernel,
                        dim3(((w + kUpTw - 1) / kUpTw) * ((h + kUpTh - 1) / kUpTh), (N * Ct + kUpPlanes - 1) / kUpPlanes),
                        dim3(kBlock), 0, st, dy, dfeat, dm, N * Ct);
+    return launch_status();
+}
+
+extern "C" int mvster_fpn_head_gather_fwd(const float* g, const float* base, float* out, int N, int h, int w,
+                                          mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(g); MVSTER_REQUIRE_PTR(base); MVSTER_REQUIRE_PTR(out);
+    MVSTER_REQUIRE_SHAPE(N > 0 && N <= 65535 && h > 1 && w > 1 && (long long)4 * h * w <= kMaxPlane);
+    const HeadDims dm{N, h, w, 2 * h, 2 * w, (float)(h - 1) / (float)(2 * h - 1), (float)(w - 1) / (float)(2 * w - 1)};
+    const dim3 grid(((dm.W + kHeadTw - 1) / kHeadTw) * ((dm.H + kHeadTh - 1) / kHeadTh), N);
+    hipLaunchKernelGGL(fpn_head_gather_fwd_kernel, grid, dim3(kBlock), 0, as_stream(stream), g, base, out, dm);
+    return launch_status();
+}
+
+extern "C" int mvster_fpn_head_gather_bwd(const float* dy, float* dg, int N, int h, int w, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(dy); MVSTER_REQUIRE_PTR(dg);
+    MVSTER_REQUIRE_SHAPE(N > 0 && (long long)N * kHeadCo <= 65535 && h > 1 && w > 1 && (long long)4 * h * w <= kMaxPlane);
+    const HeadDims dm{N, h, w, 2 * h, 2 * w, (float)(h - 1) / (float)(2 * h - 1), (float)(w - 1) / (float)(2 * w - 1)};
+    const dim3 grid(((w + kUpTw - 1) / kUpTw) * ((h + kUpTh - 1) / kUpTh), N * kHeadCo);
+    hipLaunchKernelGGL(fpn_head_gather_bwd_kernel, grid, dim3(kBlock), 0, as_stream(stream), dy, dg, dm);
     return launch_status();
 }

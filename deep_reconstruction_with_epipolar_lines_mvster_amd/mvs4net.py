@@ -483,6 +483,52 @@ def _top_down_merge(feat, skip, lateral):
     return _TopDownMerge.apply(feat, skip, lateral.weight, lateral.bias)
 
 
+class _HeadGather(torch.autograd.Function):
+    """out = base + sum over the nine taps of the shifted, x2-upsampled planes of g (csrc/fpn_merge.hip, head gather)."""
+
+    @staticmethod
+    def forward(ctx, g, base):
+        N, _, h, w = g.shape
+        out = torch.empty_like(base)
+        with _on(g.device):
+            _lib.call("mvster_fpn_head_gather_fwd", g.data_ptr(), base.data_ptr(), out.data_ptr(), N, h, w, _stream(g.device))
+        ctx.lowres = (N, h, w)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        N, h, w = ctx.lowres
+        dy = dy.contiguous()
+        dg = None
+        if ctx.needs_input_grad[0]:
+            dg = torch.empty(N, 72, h, w, dtype=torch.float32, device=dy.device)
+            with _on(dy.device):
+                _lib.call("mvster_fpn_head_gather_bwd", dy.data_ptr(), dg.data_ptr(), N, h, w, _stream(dy.device))
+        return dg, dy
+
+
+_FUSED_HEAD = True           # FPN4's last level without its 64-channel full-resolution map (needs the HIP convolutions)
+
+
+def _top_level_head(feat, skip, lateral, head):
+    """``head(F.interpolate(feat, x2, bilinear, align_corners=True) + lateral(skip))`` for a 1x1 ``lateral`` and a 3x3
+    bias-free ``head`` with 8 output channels, when nothing else needs the merged map (FPN4's last level,
+    models/mvs4net_utils.py:500-505).  Both steps are linear: the head's channel contraction is applied to ``feat`` at LOW
+    resolution (a 1x1 layer with 8*9 outputs, the lateral bias folded in: upsampling preserves constants), to ``skip`` as
+    one 8 -> 8 3x3 layer with the composed weights, and a gather kernel adds the nine shifted upsampled planes.  The
+    [N,64,H,W] map (472 MB per view at DTU resolution) and the passes over it never exist; gradients reach the original
+    parameters through the (tiny) weight compositions below."""
+    w4 = head.weight                                                       # [8, C, 3, 3]
+    wi = lateral.weight[:, :, 0, 0]                                        # [C, Cs]
+    wg = w4.permute(0, 2, 3, 1).reshape(72, w4.shape[1], 1, 1)             # plane co*9 + ky*3 + kx
+    bg = (w4 * lateral.bias[None, :, None, None]).sum(1).reshape(72) if lateral.bias is not None else None
+    wc = torch.einsum("ocyx,ci->oiyx", w4, wi).contiguous()                # [8, Cs, 3, 3]
+    g = _conv2d(feat, wg.contiguous(), bg, 1, 0)
+    base = _conv2d(skip, wc, None, 1, 1)
+    return _HeadGather.apply(g, base)
+
+
 def _pyramid_level(cin, cout, downsample):
     first = _ConvBNReLU2d(cin, cout, 5, 2, 2) if downsample else _ConvBNReLU2d(cin, cout, 3, 1, 1)
     rest = [_ConvBNReLU2d(cout, cout, 3, 1, 1) for _ in range(2 if downsample else 1)]
@@ -527,7 +573,14 @@ class FPN4(nn.Module):
         head_conv = lambda m, t: _conv2d(t, m.weight, m.bias, m.stride, m.padding)
         outs = {"stage1": head_conv(self.out1, feat)}
         for k, (lateral, head) in enumerate(((self.inner1, self.out2), (self.inner2, self.out3), (self.inner3, self.out4))):
-            feat = _top_down_merge(feat, skips[2 - k], lateral)
+            skip = skips[2 - k]
+            if (k == 2 and _FUSED_HEAD and _FUSED_MERGE and _MFMA_CONV and _DIRECT_CONV and feat.is_cuda
+                    and feat.dtype == torch.float32 and feat.is_contiguous() and skip.is_contiguous() and head.bias is None
+                    and tuple(head.weight.shape[:1] + head.weight.shape[2:]) == (8, 3, 3) and feat.shape[2] > 1 and feat.shape[3] > 1
+                    and tuple(skip.shape[2:]) == (2 * feat.shape[2], 2 * feat.shape[3])):
+                outs["stage4"] = _top_level_head(feat, skip, lateral, head)      # the merged map is not needed any further
+                break
+            feat = _top_down_merge(feat, skip, lateral)
             outs["stage%d" % (k + 2)] = head_conv(head, feat)
         return outs
 

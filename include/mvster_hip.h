@@ -294,6 +294,18 @@ int mvster_bn_train_bwd_nhwc(const float *dy, const float *x, const float *affin
                              long long M, int C, int relu, mvster_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * F3  top pyramid level without its 64-channel full-resolution map.
+ * replaces: `intra_feat = F.interpolate(intra_feat, x2, bilinear, align_corners=True) + self.inner3(conv0)` followed by
+ * `self.out4(intra_feat)` (models/mvs4net_utils.py:500-505) when nothing else reads intra_feat: the 3x3 layer's channel
+ * contraction is done at LOW resolution first (G = a 1x1 layer with 8*9 output channels, channel index co*9 + ky*3 + kx),
+ * and this operator gathers, per output pixel, the nine shifted bilinear samples:
+ *   out[n,co,Y,X] = base[n,co,Y,X] + sum_{ky,kx : (Y+ky-1, X+kx-1) inside} bilinear_x2(g[n, co*9+ky*3+kx])(Y+ky-1, X+kx-1)
+ *   g [N,72,h,w]   base, out, dy [N,8,2h,2w] (base = the 8 -> 8 layer on conv0 with the composed weights; out may alias base)
+ *   _bwd: dg [N,72,h,w] from dy (d base = dy). */
+int mvster_fpn_head_gather_fwd(const float *g, const float *base, float *out, int N, int h, int w, mvster_stream_t stream);
+int mvster_fpn_head_gather_bwd(const float *dy, float *dg, int N, int h, int w, mvster_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * F2/F3  many-channel convolutions on the fp32 matrix cores (csrc/conv_mfma.hip), NCHW fp32, padding K/2:
  * (K, stride) in {(1,1), (3,1), (3,2), (5,2)}.  replaces: nn.Conv2d / the nn.Conv3d layers run as conv2d over depth
  * slices in FPN4 (models/mvs4net_utils.py:441-455,466-470) and reg2d (models/mvs4net_utils.py:891-899).

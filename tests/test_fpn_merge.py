@@ -106,3 +106,35 @@ def test_fpn4_one_pass_over_all_views_equals_one_pass_per_view():
             assert int(p) == int(q) == views, n
         else:
             _close(p, q, "buffer " + n, rel=1e-5)
+
+
+@pytest.mark.parametrize("N,h,w", [(2, 13, 17), (1, 24, 40), (3, 9, 33)])
+def test_top_level_head_matches_the_operator_sequence(N, h, w):
+    """FPN4's last level computed without the 64-channel full-resolution map (channel contraction at low resolution +
+    gather of nine shifted upsampled planes, csrc/fpn_merge.hip) vs the reference's operator sequence
+    (models/mvs4net_utils.py:500-505) in float64: output and the gradients of feat, conv0, inner3.weight/bias, out4.weight."""
+    import torch.nn as nn
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N * 100 + h + w)
+    feat, skip = torch.randn(N, 64, h, w, generator=g), torch.randn(N, 8, 2 * h, 2 * w, generator=g)
+    lateral, head = nn.Conv2d(8, 64, 1, bias=True), nn.Conv2d(64, 8, 3, padding=1, bias=False)
+    with torch.no_grad():
+        lateral.bias.copy_(torch.randn(64, generator=g))
+    gy = torch.randn(N, 8, 2 * h, 2 * w, generator=g)
+    lat64, head64 = nn.Conv2d(8, 64, 1).double(), nn.Conv2d(64, 8, 3, padding=1, bias=False).double()
+    lat64.load_state_dict({k: v.double() for k, v in lateral.state_dict().items()})
+    head64.load_state_dict({k: v.double() for k, v in head.state_dict().items()})
+    fr, sr = feat.double().requires_grad_(True), skip.double().requires_grad_(True)
+    want = head64(F.interpolate(fr, scale_factor=2, mode="bilinear", align_corners=True) + lat64(sr))
+    (want * gy.double()).sum().backward()
+    lateral, head = lateral.to(dev), head.to(dev)
+    fg, sg = feat.to(dev).requires_grad_(True), skip.to(dev).requires_grad_(True)
+    got = mvs4net._top_level_head(fg, sg, lateral, head)
+    (got * gy.to(dev)).sum().backward()
+    tag = "head N%d %dx%d" % (N, h, w)
+    _close(got, want, tag + " out4", rel=5e-6)
+    _close(fg.grad, fr.grad, tag + " d/d feat", rel=1e-5)
+    _close(sg.grad, sr.grad, tag + " d/d conv0", rel=1e-5)
+    _close(lateral.weight.grad, lat64.weight.grad, tag + " d/d inner3.weight", rel=2e-5)
+    _close(lateral.bias.grad, lat64.bias.grad, tag + " d/d inner3.bias", rel=2e-5)
+    _close(head.weight.grad, head64.weight.grad, tag + " d/d out4.weight", rel=2e-5)
