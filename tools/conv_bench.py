@@ -25,7 +25,8 @@ LAYERS = [  # name, N, Cin, Cout, k, stride, h, w (input size); stride 0 = trans
     ("fpn conv2.0 16->32 5x5 s2", V, 16, 32, 5, 2, H // 2, W // 2), ("fpn conv2.x 32->32", V, 32, 32, 3, 1, H // 4, W // 4),
     ("fpn conv3.0 32->64 5x5 s2", V, 32, 64, 5, 2, H // 4, W // 4), ("fpn conv3.x 64->64", V, 64, 64, 3, 1, H // 8, W // 8),
     ("fpn out1 64->64 1x1", V, 64, 64, 1, 1, H // 8, W // 8), ("fpn out2 64->32", V, 64, 32, 3, 1, H // 4, W // 4),
-    ("fpn out3 64->16", V, 64, 16, 3, 1, H // 2, W // 2), ("fpn out4 64->8", V, 64, 8, 3, 1, H, W),
+    ("fpn out3 64->16", V, 64, 16, 3, 1, H // 2, W // 2), ("fpn out4 64->8 (unfused head)", V, 64, 8, 3, 1, H, W),
+    ("fpn head 64->72 1x1, low res", V, 64, 72, 1, 1, H // 2, W // 2),
     ("reg s4 conv0 4->8", 4, 4, 8, 3, 1, H, W), ("reg s4 conv1 8->16 s2", 4, 8, 16, 3, 2, H, W),
     ("reg s4 conv2 48->16", 4, 48, 16, 3, 1, H // 2, W // 2), ("reg s4 conv3 16->32 s2", 4, 16, 32, 3, 2, H // 2, W // 2),
     ("reg s4 conv4 96->32", 4, 96, 32, 3, 1, H // 4, W // 4), ("reg s4 conv5 32->64 s2", 4, 32, 64, 3, 2, H // 4, W // 4),
