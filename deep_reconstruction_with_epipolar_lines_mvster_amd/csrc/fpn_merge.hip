@@ -226,8 +226,9 @@ fpn_upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dfeat,
 //                   + conv3x3(conv0, W4 o W_inner3)(Y,X)                                              (an 8 -> 8 layer, `base`)
 // Same function, different association: the 64-channel full-resolution tensor and the five passes over it (merge forward,
 // three merge-backward passes, the 64 -> 8 layer's three operations) disappear, the flops drop 4x.
-// Forward: a workgroup owns a 32 x 8 output tile, stages the <= 8 x 20 low-resolution window of all 72 planes in LDS and
-// every lane interpolates its pixel's nine shifted samples of eight channels from there.
+// Forward: a workgroup owns a 32 x 8 output tile and walks the eight output channels: the <= 8 x 20 low-resolution window of
+// a channel's nine tap planes goes through LDS (double-buffered, the next channel's window in flight in registers) and every
+// lane interpolates its pixel's nine shifted samples from there; the 36 offsets and weights are per lane, not per channel.
 constexpr int kHeadTaps = 9, kHeadCo = 8, kHeadPlanes = kHeadTaps * kHeadCo;
 constexpr int kHeadTw = 32, kHeadTh = 8;
 constexpr int kHeadLw = 20, kHeadLh = 8;       // low-resolution window of a tile plus its one-pixel ring: <= 19 x 7 (scale < 1/2)
@@ -237,9 +238,12 @@ struct HeadDims {
     float sy, sx;
 };
 
+constexpr int kHeadWin = kHeadLh * kHeadLw;
+constexpr int kHeadLoads = (kHeadTaps * kHeadWin + kBlock - 1) / kBlock;   // window elements of one output channel's nine planes per lane
+
 __global__ void __launch_bounds__(kBlock)
 fpn_head_gather_fwd_kernel(const float* __restrict__ g, const float* __restrict__ base, float* __restrict__ out, HeadDims dm) {
-    __shared__ float win[kHeadPlanes][kHeadLh * kHeadLw];
+    __shared__ float win[2][kHeadTaps][kHeadWin];                  // one output channel's nine tap planes, double-buffered
     const int n = blockIdx.y;
     const int tiles_x = (dm.W + kHeadTw - 1) / kHeadTw;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -247,48 +251,66 @@ fpn_head_gather_fwd_kernel(const float* __restrict__ g, const float* __restrict_
     const int i_lo = source_index(max(Y0 - 1, 0), dm.sy, dm.h).i0, j_lo = source_index(max(X0 - 1, 0), dm.sx, dm.w).i0;
     const int hw = dm.h * dm.w, HW = dm.H * dm.W;
     const float* __restrict__ gn = g + (size_t)n * kHeadPlanes * hw;
-    for (int e = threadIdx.x; e < kHeadPlanes * kHeadLh * kHeadLw; e += kBlock) {
-        const int plane = e / (kHeadLh * kHeadLw), rem = e - plane * (kHeadLh * kHeadLw);
+    // this lane's window elements: the same positions for every output channel (its planes are 9 * hw further on)
+    int goff[kHeadLoads];
+#pragma unroll
+    for (int k = 0; k < kHeadLoads; ++k) {
+        const int e = threadIdx.x + kBlock * k;
+        const int tap = e / kHeadWin, rem = e - tap * kHeadWin;
         const int r = rem / kHeadLw, c = rem - r * kHeadLw;
         const int i = i_lo + r, j = j_lo + c;
-        win[plane][rem] = i < dm.h && j < dm.w ? gn[(size_t)plane * hw + (size_t)i * dm.w + j] : 0.0f;
+        goff[k] = e < kHeadTaps * kHeadWin && i < dm.h && j < dm.w ? tap * hw + i * dm.w + j : -1;
     }
-    __syncthreads();
     const int ly = threadIdx.x / kHeadTw, lx = threadIdx.x - ly * kHeadTw;
-    const int Y = Y0 + ly, X = X0 + lx;
-    if (Y >= dm.H || X >= dm.W) return;
-    Lerp py[3], px[3];
-    bool oky[3], okx[3];
+    const int Y = min(Y0 + ly, dm.H - 1), X = min(X0 + lx, dm.W - 1);
+    const bool live = Y0 + ly < dm.H && X0 + lx < dm.W;
+    int off[3][3][4];
+    float wgt[3][3][4];                                            // zero weights for the taps that leave the image
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int yy = Y + k - 1, xx = X + k - 1;
-        oky[k] = yy >= 0 && yy < dm.H;
-        okx[k] = xx >= 0 && xx < dm.W;
-        py[k] = source_index(oky[k] ? yy : Y, dm.sy, dm.h);
-        px[k] = source_index(okx[k] ? xx : X, dm.sx, dm.w);
-        py[k].i0 -= i_lo; py[k].i1 -= i_lo;
-        px[k].i0 -= j_lo; px[k].i1 -= j_lo;
-    }
-    float acc[kHeadCo];
-    const size_t o = (size_t)n * kHeadCo * HW + (size_t)Y * dm.W + X;
-#pragma unroll
-    for (int co = 0; co < kHeadCo; ++co) acc[co] = base[o + (size_t)co * HW];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = Y + ky - 1;
+        const bool oky = yy >= 0 && yy < dm.H;
+        Lerp py = source_index(oky ? yy : Y, dm.sy, dm.h);
+        py.i0 -= i_lo; py.i1 -= i_lo;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            if (!(oky[ky] && okx[kx])) continue;
-            const int o00 = py[ky].i0 * kHeadLw + px[kx].i0, o01 = py[ky].i0 * kHeadLw + px[kx].i1;
-            const int o10 = py[ky].i1 * kHeadLw + px[kx].i0, o11 = py[ky].i1 * kHeadLw + px[kx].i1;
-            const float w00 = py[ky].l0 * px[kx].l0, w01 = py[ky].l0 * px[kx].l1, w10 = py[ky].l1 * px[kx].l0, w11 = py[ky].l1 * px[kx].l1;
-#pragma unroll
-            for (int co = 0; co < kHeadCo; ++co) {
-                const float* __restrict__ p = win[co * kHeadTaps + ky * 3 + kx];
-                acc[co] += (w00 * p[o00] + w01 * p[o01]) + (w10 * p[o10] + w11 * p[o11]);
-            }
+            const int xx = X + kx - 1;
+            const bool ok = oky && xx >= 0 && xx < dm.W;
+            Lerp px = source_index(xx >= 0 && xx < dm.W ? xx : X, dm.sx, dm.w);
+            px.i0 -= j_lo; px.i1 -= j_lo;
+            const int t = (ky * 3 + kx) * kHeadWin;
+            off[ky][kx][0] = t + py.i0 * kHeadLw + px.i0; off[ky][kx][1] = t + py.i0 * kHeadLw + px.i1;
+            off[ky][kx][2] = t + py.i1 * kHeadLw + px.i0; off[ky][kx][3] = t + py.i1 * kHeadLw + px.i1;
+            wgt[ky][kx][0] = ok ? py.l0 * px.l0 : 0.0f; wgt[ky][kx][1] = ok ? py.l0 * px.l1 : 0.0f;
+            wgt[ky][kx][2] = ok ? py.l1 * px.l0 : 0.0f; wgt[ky][kx][3] = ok ? py.l1 * px.l1 : 0.0f;
         }
+    }
+    float v[kHeadLoads];
+    auto fetch = [&](int co) {
+        const float* __restrict__ p = gn + (size_t)co * kHeadTaps * hw;
 #pragma unroll
-    for (int co = 0; co < kHeadCo; ++co) out[o + (size_t)co * HW] = acc[co];
+        for (int k = 0; k < kHeadLoads; ++k) v[k] = goff[k] >= 0 ? p[goff[k]] : 0.0f;
+    };
+    fetch(0);
+    const size_t o = (size_t)n * kHeadCo * HW + (size_t)Y * dm.W + X;
+    for (int co = 0; co < kHeadCo; ++co) {
+        float* __restrict__ w = &win[co & 1][0][0];
+#pragma unroll
+        for (int k = 0; k < kHeadLoads; ++k) {
+            const int e = threadIdx.x + kBlock * k;
+            if (e < kHeadTaps * kHeadWin) w[e] = v[k];
+        }
+        __syncthreads();                                           // (the other buffer was last read two channels ago)
+        if (co + 1 < kHeadCo) fetch(co + 1);
+        float acc = live ? base[o + (size_t)co * HW] : 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                acc += (wgt[ky][kx][0] * w[off[ky][kx][0]] + wgt[ky][kx][1] * w[off[ky][kx][1]]) +
+                       (wgt[ky][kx][2] * w[off[ky][kx][2]] + wgt[ky][kx][3] * w[off[ky][kx][3]]);
+        if (live) out[o + (size_t)co * HW] = acc;
+    }
 }
 
 // Backward of the gather w.r.t. G: dG[(co,tap)] = transposed upsample of dy[co] shifted by the tap.  Same tiling as
