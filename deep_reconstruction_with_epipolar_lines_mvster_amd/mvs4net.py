@@ -4,10 +4,12 @@ Same constructor keywords, ``forward(imgs, proj_matrices, depth_values, filename
 dictionary and sub-module / parameter names (``feature``, ``reg``, ``mono_depth_decoder``, ``stagenet`` ...), so
 reference checkpoints load with ``strict=True`` and ``train_mvs4.py`` / ``test_mvs4.py`` run unchanged.
 
-Only the stage body is ours (``hotpath.stagenet`` + the hypothesis-scheduling kernels).  The feature pyramid,
-the 3-D regulariser and the monocular head are OUT OF SCOPE for kernels: they are
-stock ``torch.nn`` convolutions (MIOpen on ROCm), re-stated here only so that the shell is self-contained; their
-layer shapes and parameter names follow models/mvs4net_utils.py:123-130,230-256,426-509,840-882,884-926.
+The stage body is ``hotpath.stagenet`` + the hypothesis-scheduling kernels.  The
+feature pyramid, the 3-D regulariser and the monocular head (section 8f rows F2, F3) keep the reference's modules,
+parameter names and layer shapes (models/mvs4net_utils.py:123-130,230-256,426-509,840-882,884-926) -- so that
+checkpoints load -- while their operators run on HIP kernels behind the C ABI: BatchNorm+ReLU (csrc/batchnorm.hip),
+the FPN top-down merge and top-level head (csrc/fpn_merge.hip), the convolutions (csrc/conv_direct.hip,
+csrc/conv_mfma.hip; one operation of one layer stays on MIOpen on measured merit, see ``_conv_route``).
 """
 import torch
 import torch.nn as nn
@@ -20,7 +22,7 @@ __all__ = ["MVS4net", "FPN4", "reg2d", "mono_depth_decoder"]
 
 
 # --------------------------------------------------------------------------------------------------
-# stock PyTorch building blocks (out of scope for HIP kernels; parameter names match the reference)
+# building blocks: the reference's modules and parameter names, operators on the HIP kernels
 # --------------------------------------------------------------------------------------------------
 class _BNReLUTrain(torch.autograd.Function):
     """Training-mode BatchNorm (+ReLU) as two streaming HIP passes each way (csrc/batchnorm.hip).  ``groups`` > 1: the
