@@ -27,6 +27,12 @@ namespace mvster {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef MVSTER_MF_CB_S1         // input channels staged per chunk by the stride-1 forward kernels.  Measured (TFLOP/s forward,
+#define MVSTER_MF_CB_S1 8       // 32->32 / 64->32 / 96->32 / 1x1 64->72): 4: 85 / 99 / 102 / 36, 8: 83 / 97 / 100 / 39, 16: 70 / 88 / 91 / 39
+#endif
+#ifndef MVSTER_MF_FWD_WAVES     // > 0: ask the compiler for at least this many waves per SIMD in the forward kernels
+#define MVSTER_MF_FWD_WAVES 0   // (3 instead of the natural 2 at 64 output channels: within 2 % either way)
+#endif
 constexpr int kMfTileW = 32;          // output pixels per MFMA column block
 constexpr int kMfRowsFwd = 8;         // output rows per forward tile: two per wave
 
@@ -88,6 +94,9 @@ struct FwdTile {
 
 template <int KS, int S, int NB, int CB>
 __global__ void __launch_bounds__(kBlock)
+#if MVSTER_MF_FWD_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(MVSTER_MF_FWD_WAVES)))
+#endif
 conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                      float* __restrict__ y, MfDims d) {
     using T = FwdTile<KS, S, NB, CB>;
@@ -706,7 +715,7 @@ extern "C" long long mvster_conv_mfma_workspace(int N, int Cin, int Cout, int H,
         const WgPlan pl = wgrad_plan(N, Cin, Cout, Ho, Wo, K, stride);
         return (long long)pl.groups * pl.grid_x * pl.E;
     }
-    const int cb = stride == 1 ? 8 : 4;
+    const int cb = stride == 1 ? MVSTER_MF_CB_S1 : 4;
     return (long long)((Cin + cb - 1) / cb * cb) * K * K * ((Cout + 31) / 32 * 32);
 }
 
@@ -723,7 +732,7 @@ static int conv_mfma_fwd_impl(const float* x, const float* weight, const float* 
     if (!mvster_conv_mfma_supported(Cin, Cout, K, stride)) return MVSTER_ERR_UNSUPPORTED;
     MVSTER_REQUIRE_SHAPE(pack_mode == 0 || stride == 1);
     MVSTER_REQUIRE_SHAPE(workspace_floats >= mvster_conv_mfma_workspace(N, Cin, Cout, H, W, K, stride, MVSTER_CONV_OP_FWD));
-    const int P = K / 2, cb = stride == 1 ? 8 : 4;
+    const int P = K / 2, cb = stride == 1 ? MVSTER_MF_CB_S1 : 4;
     MfDims d;
     d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.depth = depth; d.Creal = Creal;
     d.Ho = (H + 2 * P - K) / stride + 1;
@@ -740,8 +749,8 @@ static int conv_mfma_fwd_impl(const float* x, const float* weight, const float* 
                        K * K, d.CinPad, d.CoutPad, pack_mode);
     const bool two = d.CoutPad % 64 == 0;                          // 64 output channels per workgroup when they divide
     const dim3 grid((unsigned)tiles, d.CoutPad / (two ? 64 : 32));
-    if (K == 1) { if (two) MVSTER_MFMA_FWD(1, 1, 2, 8); else MVSTER_MFMA_FWD(1, 1, 1, 8); }
-    else if (K == 3 && stride == 1) { if (two) MVSTER_MFMA_FWD(3, 1, 2, 8); else MVSTER_MFMA_FWD(3, 1, 1, 8); }
+    if (K == 1) { if (two) MVSTER_MFMA_FWD(1, 1, 2, MVSTER_MF_CB_S1); else MVSTER_MFMA_FWD(1, 1, 1, MVSTER_MF_CB_S1); }
+    else if (K == 3 && stride == 1) { if (two) MVSTER_MFMA_FWD(3, 1, 2, MVSTER_MF_CB_S1); else MVSTER_MFMA_FWD(3, 1, 1, MVSTER_MF_CB_S1); }
     else if (K == 3) { if (two) MVSTER_MFMA_FWD(3, 2, 2, 4); else MVSTER_MFMA_FWD(3, 2, 1, 4); }
     else { if (two) MVSTER_MFMA_FWD(5, 2, 2, 4); else MVSTER_MFMA_FWD(5, 2, 1, 4); }
     return launch_status();
