@@ -107,7 +107,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const double* __
 template <bool RELU>
 __global__ void __launch_bounds__(kBlock)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ affine, const float* __restrict__ save_mean,
-                float* __restrict__ y, int C, int HW, int Ng) {
+                const float* __restrict__ residual, float* __restrict__ y, int C, int HW, int Ng) {
     const int c = blockIdx.y, n = blockIdx.z;
     const int gc = (n / Ng) * C + c;
     const float a = affine[2 * gc], b = affine[2 * gc + 1], mean = save_mean[gc];
@@ -121,12 +121,17 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ affine, c
             float4 v = *reinterpret_cast<const float4*>(x + off + i);
             v.x = fmaf(v.x - mean, a, b); v.y = fmaf(v.y - mean, a, b); v.z = fmaf(v.z - mean, a, b); v.w = fmaf(v.w - mean, a, b);
             if (RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+            if (residual != nullptr) {                             // y = relu(bn(x)) + residual: the skip connections of reg2d
+                const float4 r = *reinterpret_cast<const float4*>(residual + off + i);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
             *reinterpret_cast<float4*>(y + off + i) = v;
         } else {
             for (int k = 0; k < kBnVec; ++k)
                 if (i + k < HW) {
-                    const float v = fmaf(x[off + i + k] - mean, a, b);
-                    y[off + i + k] = RELU ? fmaxf(v, 0.0f) : v;
+                    float v = fmaf(x[off + i + k] - mean, a, b);
+                    if (RELU) v = fmaxf(v, 0.0f);
+                    y[off + i + k] = residual != nullptr ? v + residual[off + i + k] : v;
                 }
         }
     }
@@ -383,10 +388,10 @@ static int check_bn(int N, int C, int HW) {
 
 }  // namespace mvster
 
-extern "C" int mvster_bn_train_fwd_grouped(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
-                                           float* save_invstd, float* running_mean, float* running_var, double* sums,
-                                           float* affine, int N, int C, int HW, int groups, float momentum, float eps,
-                                           int relu, mvster_stream_t stream) {
+extern "C" int mvster_bn_train_fwd_grouped(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                                           float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                           double* sums, float* affine, int N, int C, int HW, int groups, float momentum,
+                                           float eps, int relu, mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(save_mean); MVSTER_REQUIRE_PTR(save_invstd);
     MVSTER_REQUIRE_PTR(sums); MVSTER_REQUIRE_PTR(affine);
@@ -400,8 +405,8 @@ extern "C" int mvster_bn_train_fwd_grouped(const float* x, const float* gamma, c
     hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBlock), 0, st, x, sums, C, HW, Ng);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid_for(C, 64)), dim3(64), 0, st, x, sums, gamma, beta, save_mean,
                        save_invstd, running_mean, running_var, affine, C, HW, Ng, groups, (double)Ng * HW, momentum, eps);
-    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true>), grid, dim3(kBlock), 0, st, x, affine, save_mean, y, C, HW, Ng);
-    else hipLaunchKernelGGL((bn_apply_kernel<false>), grid, dim3(kBlock), 0, st, x, affine, save_mean, y, C, HW, Ng);
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true>), grid, dim3(kBlock), 0, st, x, affine, save_mean, residual, y, C, HW, Ng);
+    else hipLaunchKernelGGL((bn_apply_kernel<false>), grid, dim3(kBlock), 0, st, x, affine, save_mean, residual, y, C, HW, Ng);
     return launch_status();
 }
 
@@ -409,8 +414,8 @@ extern "C" int mvster_bn_train_fwd(const float* x, const float* gamma, const flo
                                    float* save_invstd, float* running_mean, float* running_var, double* sums,
                                    float* affine, int N, int C, int HW, float momentum, float eps, int relu,
                                    mvster_stream_t stream) {
-    return mvster_bn_train_fwd_grouped(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, sums, affine, N, C,
-                                       HW, 1, momentum, eps, relu, stream);
+    return mvster_bn_train_fwd_grouped(x, gamma, beta, nullptr, y, save_mean, save_invstd, running_mean, running_var, sums, affine,
+                                       N, C, HW, 1, momentum, eps, relu, stream);
 }
 
 extern "C" int mvster_bn_train_bwd_grouped(const float* dy, const float* x, const float* affine, const float* save_mean,

@@ -29,7 +29,7 @@ class _BNReLUTrain(torch.autograd.Function):
     batch is that many runs of consecutive samples, each normalised with its own statistics (NCHW only)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, groups=1):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, groups=1, residual=None):
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         dev = x.device
@@ -46,16 +46,17 @@ class _BNReLUTrain(torch.autograd.Function):
                           save_mean.data_ptr(), save_invstd.data_ptr(), opt(running_mean), opt(running_var),
                           sums.data_ptr(), affine.data_ptr(), N * HW, C, float(momentum), float(eps),
                           1 if relu else 0, _stream(dev))
-            elif groups == 1:
+            elif groups == 1 and residual is None:
                 _lib.call("mvster_bn_train_fwd", x.data_ptr(), opt(weight), opt(bias), y.data_ptr(), save_mean.data_ptr(),
                           save_invstd.data_ptr(), opt(running_mean), opt(running_var), sums.data_ptr(), affine.data_ptr(),
                           N, C, HW, float(momentum), float(eps), 1 if relu else 0, _stream(dev))
             else:
-                _lib.call("mvster_bn_train_fwd_grouped", x.data_ptr(), opt(weight), opt(bias), y.data_ptr(),
+                _lib.call("mvster_bn_train_fwd_grouped", x.data_ptr(), opt(weight), opt(bias), opt(residual), y.data_ptr(),
                           save_mean.data_ptr(), save_invstd.data_ptr(), opt(running_mean), opt(running_var), sums.data_ptr(),
                           affine.data_ptr(), N, C, HW, groups, float(momentum), float(eps), 1 if relu else 0, _stream(dev))
         ctx.save_for_backward(x, affine, save_mean, save_invstd)
         ctx.cfg = (bool(relu), weight is not None, bias is not None, nhwc, groups)
+        ctx.has_residual = residual is not None
         return y
 
     @staticmethod
@@ -84,11 +85,13 @@ class _BNReLUTrain(torch.autograd.Function):
                 _lib.call("mvster_bn_train_bwd_grouped", dy.data_ptr(), x.data_ptr(), affine.data_ptr(), save_mean.data_ptr(),
                           save_invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), sums.data_ptr(),
                           N, C, HW, groups, 1 if relu else 0, _stream(dev))
-        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None
+        return (dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None,
+                dy if ctx.has_residual else None)
 
 
-def _batch_norm(bn, x, relu=False, groups=1):
-    """Batch normalisation (+ optional ReLU) with the module's parameters/buffers.  ``groups`` > 1 (training mode): the
+def _batch_norm(bn, x, relu=False, groups=1, residual=None):
+    """Batch normalisation (+ optional ReLU, + optional ``residual`` added after it: the skip connections of reg2d, folded
+    into the normalisation pass) with the module's parameters/buffers.  ``groups`` > 1 (training mode): the
     batch holds that many runs of consecutive samples that the reference would have pushed through one after the other
     (the views of MVS4net.forward) -- each run gets its own statistics and the running statistics one update per run.
 
@@ -102,7 +105,8 @@ def _batch_norm(bn, x, relu=False, groups=1):
         if x.shape[0] % groups:
             raise ValueError("batch of %d samples does not split into %d statistic groups" % (x.shape[0], groups))
         if not (_BN_IMPL == "hip" and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and bn.momentum is not None):
-            return torch.cat([_batch_norm(bn, part, relu) for part in x.chunk(groups, 0)], 0)
+            y = torch.cat([_batch_norm(bn, part, relu) for part in x.chunk(groups, 0)], 0)
+            return y if residual is None else y + residual
     else:
         groups = 1
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -113,12 +117,15 @@ def _batch_norm(bn, x, relu=False, groups=1):
     if fused:
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
-        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu, groups)
+        if residual is not None and (not x.is_contiguous() or not residual.is_contiguous() or residual.shape != x.shape):
+            return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu, groups) + residual
+        return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu, groups, residual)
     if x.is_cuda and _BN_IMPL == "native":
         y = torch.native_batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps)[0]
     else:
         y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
-    return F.relu(y, inplace=True) if relu else y
+    y = F.relu(y, inplace=True) if relu else y
+    return y if residual is None else y + residual
 
 
 _BN_IMPL = "hip"             # "hip" (csrc/batchnorm.hip for training mode), "miopen" (F.batch_norm) or "native" (ATen)
@@ -633,14 +640,15 @@ class reg2d(nn.Module):
         return self.prob(y).squeeze(1)
 
     @staticmethod
-    def _up(seq, x2d):
+    def _up(seq, x2d, skip=None):
+        """up-convolution -> BatchNorm -> ReLU (+ ``skip``: ``conv_k + self.conv_j(x)``, models/mvs4net_utils.py:921-923)"""
         deconv, bn = seq[0], seq[1]
         if deconv.stride[1:] == (2, 2) and deconv.padding[1:] == (1, 1) and deconv.output_padding[1:] == (1, 1):
             y = _conv_transpose2d_x2(x2d, deconv.weight[:, :, 0].contiguous())
         else:
             y = F.conv_transpose2d(x2d, deconv.weight[:, :, 0], None, stride=deconv.stride[1:], padding=deconv.padding[1:],
                                    output_padding=deconv.output_padding[1:])
-        return _batch_norm(bn, y, relu=True)
+        return _batch_norm(bn, y, relu=True, residual=skip)
 
     def forward_slices(self, x):
         """Same network, same parameters, with the D depth slices stacked into the batch: every layer is a 2-D
@@ -652,9 +660,9 @@ class reg2d(nn.Module):
         e1 = self.conv2.forward_slices(self.conv1.forward_slices(e0, B, D), B, D)
         e2 = self.conv4.forward_slices(self.conv3.forward_slices(e1, B, D), B, D)
         y = self.conv6.forward_slices(self.conv5.forward_slices(e2, B, D), B, D)
-        y = e2 + self._up(self.conv7, y)
-        y = e1 + self._up(self.conv9, y)
-        y = e0 + self._up(self.conv11, y)
+        y = self._up(self.conv7, y, e2)
+        y = self._up(self.conv9, y, e1)
+        y = self._up(self.conv11, y, e0)
         y = _conv2d(y, self.prob.weight[:, :, 0], self.prob.bias)
         return y.view(B, D, H, W)
 

@@ -274,11 +274,13 @@ int mvster_bn_train_bwd(const float *dy, const float *x, const float *affine, co
  *   save_mean, save_invstd : [groups,C]; affine : [groups,C,2]; sums : [groups,C,2] double scratch.
  *   running_mean/var [C] receive the groups' updates one after the other, in group order (as the reference's successive
  *   calls do); dgamma/dbeta [C] are summed over the groups.  groups = 1 is mvster_bn_train_fwd/bwd.
+ *   residual (may be NULL): y = relu?(bn(x)) + residual, same shape as x -- reg2d's skip connections
+ *   (`x = conv2 + self.conv9(x)`, models/mvs4net_utils.py:921-923) without a separate add pass; its gradient is dy itself.
  *   N % groups != 0 -> MVSTER_ERR_SHAPE. */
-int mvster_bn_train_fwd_grouped(const float *x, const float *gamma, const float *beta, float *y, float *save_mean,
-                                float *save_invstd, float *running_mean, float *running_var, double *sums,
-                                float *affine, int N, int C, int HW, int groups, float momentum, float eps, int relu,
-                                mvster_stream_t stream);
+int mvster_bn_train_fwd_grouped(const float *x, const float *gamma, const float *beta, const float *residual, float *y,
+                                float *save_mean, float *save_invstd, float *running_mean, float *running_var,
+                                double *sums, float *affine, int N, int C, int HW, int groups, float momentum,
+                                float eps, int relu, mvster_stream_t stream);
 int mvster_bn_train_bwd_grouped(const float *dy, const float *x, const float *affine, const float *save_mean,
                                 const float *save_invstd, float *dx, float *dgamma, float *dbeta, double *sums, int N,
                                 int C, int HW, int groups, int relu, mvster_stream_t stream);
