@@ -621,6 +621,138 @@ conv_mfma_wgrad_packed_kernel(const float* __restrict__ x, const float* __restri
     for (int e = tid; e < E; e += kBlock) out[e] = lds[e];
 }
 
+// Weight gradient of the 1x1 layers: dW[co][ci] = sum_p dy[co][p] x[ci][p] -- a plain GEMM whose K runs over the pixels.  The
+// tap-row kernel above gives a 1x1 layer ONE MFMA per pair of LDS tiles, and every (co, ci) block group re-reads both tensors
+// (FPN4's head contraction 64 -> 72 at half resolution: 6 groups, 3.5 GB of loads for 1.25 GB of tensors, 0.85 ms).  Here a
+// workgroup holds up to 96 x 64 outputs (3 x 2 accumulators per wave) and reads its 4 x 32 pixels of both tensors once.
+constexpr int kW1Rows = 4, kW1Px = kW1Rows * kMfTileW;             // pixels per tile: one row per wave
+constexpr int kW1Ps = kW1Px + 1;                                   // plane stride, odd: the 32 channels of a lane group on 32 banks
+
+template <int COB, int CIBK>
+__global__ void __launch_bounds__(kBlock)
+conv_mfma_wgrad_1x1_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partials, MfWgDims d) {
+    constexpr int CO = COB * 32, CI = CIBK * 32, E = COB * CIBK * 1024;
+    constexpr int PD = CO / 4, PX = CI / 4, NP = kW1Px / kWave;    // planes per wave, elements of a plane per lane
+    extern __shared__ float lds[];                                 // max((CO + CI) * kW1Ps, E) floats
+    float* __restrict__ dyl = lds;
+    float* __restrict__ xl = lds + CO * kW1Ps;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
+    const int cog = blockIdx.y / d.ci_blocks, cig = blockIdx.y - cog * d.ci_blocks;
+    const int co0 = cog * CO, ci0 = cig * CI;
+    const int HW = d.H * d.W;
+    f32x16 acc[COB][CIBK];
+#pragma unroll
+    for (int a = 0; a < COB; ++a)
+#pragma unroll
+        for (int b = 0; b < CIBK; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    float vd[PD][NP], vx[PX][NP];
+    auto fetch = [&](int t) {
+        const int tx = t % d.tiles_x;
+        t /= d.tiles_x;
+        const int ty = t % d.tiles_y, n = t / d.tiles_y;
+        int off[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int idx = lane + kWave * k;
+            const int gy = ty * kW1Rows + idx / kMfTileW, gx = tx * kMfTileW + idx % kMfTileW;
+            off[k] = gy < d.H && gx < d.W ? gy * d.W + gx : -1;
+        }
+#pragma unroll
+        for (int pp = 0; pp < PD; ++pp) {
+            const int co = co0 + wave * PD + pp;
+            const float* __restrict__ plane = dy + ((size_t)n * d.Cout + co) * HW;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) vd[pp][k] = co < d.Cout && off[k] >= 0 ? plane[off[k]] : 0.0f;
+        }
+#pragma unroll
+        for (int pp = 0; pp < PX; ++pp) {
+            const int ci = ci0 + wave * PX + pp;
+            const float* __restrict__ plane = x + ((size_t)n * d.Cin + ci) * HW;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) vx[pp][k] = ci < d.Cin && off[k] >= 0 ? plane[off[k]] : 0.0f;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int pp = 0; pp < PD; ++pp)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) dyl[(wave * PD + pp) * kW1Ps + lane + kWave * k] = vd[pp][k];
+#pragma unroll
+        for (int pp = 0; pp < PX; ++pp)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) xl[(wave * PX + pp) * kW1Ps + lane + kWave * k] = vx[pp][k];
+    };
+    if ((int)blockIdx.x < d.ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < d.ntiles; t += gridDim.x) {
+        if (t != (int)blockIdx.x) __syncthreads();
+        stage();
+        __syncthreads();
+        if (t + (int)gridDim.x < d.ntiles) fetch(t + gridDim.x);
+#pragma unroll 4
+        for (int ox = 0; ox < kMfTileW; ox += 2) {
+            const int q = wave * kMfTileW + ox + h;                // this wave's row of the tile, pixel pair (ox, ox + 1)
+            float a[COB], b[CIBK];
+#pragma unroll
+            for (int i = 0; i < COB; ++i) a[i] = dyl[(i * 32 + p) * kW1Ps + q];
+#pragma unroll
+            for (int j = 0; j < CIBK; ++j) b[j] = xl[(j * 32 + p) * kW1Ps + q];
+#pragma unroll
+            for (int i = 0; i < COB; ++i)
+#pragma unroll
+                for (int j = 0; j < CIBK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < COB; ++i)
+#pragma unroll
+                for (int j = 0; j < CIBK; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* __restrict__ slot = &lds[((i * CIBK + j) * 16 + r) * 64 + lane];
+                        *slot = w == 0 ? acc[i][j][r] : *slot + acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ out = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * E;
+    for (int e = tid; e < E; e += kBlock) out[e] = lds[e];
+}
+
+// finish for the 1x1 kernel: e = ((i * CIBK + j) * 16 + reg) * 64 + lane -> co = cog*CO + i*32 + row(reg, lane), ci = cig*CI + j*32 + (lane & 31)
+__global__ void __launch_bounds__(kBlock)
+conv_mfma_wgrad_1x1_finish_kernel(const float* __restrict__ partials, float* __restrict__ dweight, int nparts, int E, int COB,
+                                  int CIBK, int Cin, int Cout, int ci_blocks) {
+    __shared__ float red[kBlock];
+    const int grp = blockIdx.y;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (e < E) {
+        const float* __restrict__ src = partials + (size_t)grp * nparts * E + e;
+        float part[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        int q = slice;
+        for (; q + 28 < nparts; q += 32)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[u] += src[(size_t)(q + 4 * u) * E];
+        for (; q < nparts; q += 4) part[0] += src[(size_t)q * E];
+        s = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (slice != 0 || e >= E) return;
+    s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    const int lane = e & 63, reg = (e >> 6) & 15, ij = e >> 10;
+    const int i = ij / CIBK, j = ij - i * CIBK;
+    const int cog = grp / ci_blocks, cig = grp - cog * ci_blocks;
+    const int co = cog * COB * 32 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    const int ci = cig * CIBK * 32 + j * 32 + (lane & 31);
+    if (co < Cout && ci < Cin) dweight[(size_t)co * Cin + ci] = s;
+}
+
 // dW[co][ci][ky][kx] = sum over the workgroups' partial sums; E elements per (co block, ci block) in MFMA-native order:
 // e = ((ky * NBN + j) * 16 + reg) * 64 + lane.  A workgroup = 64 elements x 4 slices of the partials.
 __global__ void __launch_bounds__(kBlock)
@@ -679,10 +811,29 @@ constexpr int kWgGridOnePerCu = 256, kWgGridTwoPerCu = 512;
 struct WgPlan {
     int cib, th, ci_blocks, co_blocks, groups, nbn, E, grid_x, tiles_x, tiles_y, ntiles;
     bool packed;                      // <= 8 output channels, 3x3 stride 1: conv_mfma_wgrad_packed_kernel
+    int cob1, cibk1;                  // K = 1: 32-channel blocks per workgroup of conv_mfma_wgrad_1x1_kernel (0: not that kernel)
 };
 
 static WgPlan wgrad_plan(int N, int Cin, int Cout, int Ho, int Wo, int K, int stride) {
     WgPlan pl;
+    pl.cob1 = pl.cibk1 = 0;
+    if (K == 1 && stride == 1) {                                   // whole-GEMM kernel: up to 96 x 64 outputs per workgroup
+        const int cob_all = (Cout + 31) / 32, cib_all = (Cin + 31) / 32;
+        pl.cob1 = cob_all >= 3 ? 3 : cob_all;
+        pl.cibk1 = cib_all >= 2 ? 2 : 1;
+        pl.cib = 32; pl.packed = false; pl.th = kW1Rows; pl.nbn = 1;
+        pl.co_blocks = (cob_all + pl.cob1 - 1) / pl.cob1;
+        pl.ci_blocks = (cib_all + pl.cibk1 - 1) / pl.cibk1;
+        pl.groups = pl.co_blocks * pl.ci_blocks;
+        pl.E = pl.cob1 * pl.cibk1 * 1024;
+        pl.tiles_x = (Wo + kMfTileW - 1) / kMfTileW;
+        pl.tiles_y = (Ho + kW1Rows - 1) / kW1Rows;
+        pl.ntiles = N * pl.tiles_x * pl.tiles_y;
+        int g1 = kWgGridOnePerCu / pl.groups;
+        if (g1 < 1) g1 = 1;
+        pl.grid_x = pl.ntiles < g1 ? pl.ntiles : g1;
+        return pl;
+    }
     pl.cib = wgrad_cib(Cin, K);
     pl.packed = K == 3 && stride == 1 && Cout <= 8;
     pl.th = pl.packed ? kPkRows : stride == 1 ? 8 : 4;
@@ -748,6 +899,11 @@ static int conv_mfma_fwd_impl(const float* x, const float* weight, const float* 
     hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
                        K * K, d.CinPad, d.CoutPad, pack_mode);
     const bool two = d.CoutPad % 64 == 0;                          // 64 output channels per workgroup when they divide
+    if (K == 1 && d.CoutPad == 96) {                               // 1x1, 65-96 output channels (FPN4's head contraction 64 -> 72):
+        const dim3 grid((unsigned)tiles, 1);                       // all three blocks from one pass over the input tile
+        MVSTER_MFMA_FWD(1, 1, 3, MVSTER_MF_CB_S1);
+        return launch_status();
+    }
     const dim3 grid((unsigned)tiles, d.CoutPad / (two ? 64 : 32));
     if (K == 1) { if (two) MVSTER_MFMA_FWD(1, 1, 2, MVSTER_MF_CB_S1); else MVSTER_MFMA_FWD(1, 1, 1, MVSTER_MF_CB_S1); }
     else if (K == 3 && stride == 1) { if (two) MVSTER_MFMA_FWD(3, 1, 2, MVSTER_MF_CB_S1); else MVSTER_MFMA_FWD(3, 1, 1, MVSTER_MF_CB_S1); }
@@ -854,6 +1010,31 @@ static int conv_mfma_wgrad_impl(const float* x, const float* dy, float* dweight,
     d.tiles_x = pl.tiles_x; d.tiles_y = pl.tiles_y; d.ntiles = pl.ntiles; d.ci_blocks = pl.ci_blocks;
     const hipStream_t st = as_stream(stream);
     const dim3 grid(pl.grid_x, pl.groups);
+    if (pl.cob1 > 0) {
+#define MVSTER_MFMA_WG_1X1(COB_, CIBK_)                                                                                    \
+    {                                                                                                                        \
+        constexpr int fl = (COB_ + CIBK_) * 32 * kW1Ps > COB_ * CIBK_ * 1024 ? (COB_ + CIBK_) * 32 * kW1Ps : COB_ * CIBK_ * 1024; \
+        constexpr int bytes = (int)sizeof(float) * fl;                                                                      \
+        if (bytes > 64 * 1024 &&                                                                                             \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wgrad_1x1_kernel<COB_, CIBK_>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {                          \
+            (void)hipGetLastError();                                                                                         \
+            return MVSTER_ERR_LAUNCH;                                                                                        \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((conv_mfma_wgrad_1x1_kernel<COB_, CIBK_>), grid, dim3(kBlock), bytes, st, x, dy, workspace, d);   \
+    }
+        if (pl.cob1 == 3 && pl.cibk1 == 2) MVSTER_MFMA_WG_1X1(3, 2)
+        else if (pl.cob1 == 3) MVSTER_MFMA_WG_1X1(3, 1)
+        else if (pl.cob1 == 2 && pl.cibk1 == 2) MVSTER_MFMA_WG_1X1(2, 2)
+        else if (pl.cob1 == 2) MVSTER_MFMA_WG_1X1(2, 1)
+        else if (pl.cibk1 == 2) MVSTER_MFMA_WG_1X1(1, 2)
+        else MVSTER_MFMA_WG_1X1(1, 1)
+#undef MVSTER_MFMA_WG_1X1
+        if (int rc = launch_status()) return rc;
+        hipLaunchKernelGGL(conv_mfma_wgrad_1x1_finish_kernel, dim3(grid_for(pl.E, 64), pl.groups), dim3(kBlock), 0, st, workspace,
+                           dweight, pl.grid_x, pl.E, pl.cob1, pl.cibk1, Cin, Cout, pl.ci_blocks);
+        return launch_status();
+    }
     if (pl.packed) {
         switch (pl.cib) {
             case 8: MVSTER_MFMA_WG_PACKED(8) break;
@@ -861,7 +1042,6 @@ static int conv_mfma_wgrad_impl(const float* x, const float* dy, float* dweight,
             default: MVSTER_MFMA_WG_PACKED(32) break;
         }
     }
-    else if (K == 1) { MVSTER_MFMA_WG_BY_CIB(1, 1, 8) }
     else if (K == 3 && stride == 1) { MVSTER_MFMA_WG_BY_CIB(3, 1, 8) }
     else if (K == 3) { MVSTER_MFMA_WG_BY_CIB(3, 2, 4) }
     else {
@@ -882,7 +1062,7 @@ extern "C" int mvster_conv_mfma_wgrad(const float* x, const float* dy, float* dw
 extern "C" int mvster_conv_mfma_depth3_wgrad(const float* x, const float* dy, float* dweight, float* workspace,
                                              long long workspace_floats, int N, int C, int Cout, int H, int W, int K, int depth,
                                              mvster_stream_t stream) {
-    MVSTER_REQUIRE_SHAPE(depth > 0 && N > 0 && N % depth == 0 && C > 0 && Cout > 0 && (K == 1 || K == 3));
-    if (K == 3 && Cout <= 8) return MVSTER_ERR_UNSUPPORTED;       // the packed-tap kernel reads real planes only
+    MVSTER_REQUIRE_SHAPE(depth > 0 && N > 0 && N % depth == 0 && C > 0 && Cout > 0);
+    if (K != 3 || Cout <= 8) return MVSTER_ERR_UNSUPPORTED;       // the 1x1 and packed-tap kernels read real planes only
     return conv_mfma_wgrad_impl(x, dy, dweight, workspace, workspace_floats, N, 3 * C, Cout, H, W, K, 1, depth, C, stream);
 }

@@ -161,7 +161,7 @@ def _conv3d_as_2d(conv, x2d, B, D):
     w2 = w.permute(0, 2, 1, 3, 4).reshape(w.shape[0], 3 * w.shape[1], w.shape[3], w.shape[4])
     k = w.shape[3]
     if (_MFMA_CONV and _DEPTH_IN_PLACE and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.is_contiguous() and conv.bias is None
-            and w.shape[3] == w.shape[4] and k in (1, 3) and tuple(stride) == (1, 1) and tuple(pad) == (k // 2, k // 2)
+            and w.shape[3] == w.shape[4] and k == 3 and tuple(stride) == (1, 1) and tuple(pad) == (1, 1)
             and w.shape[0] >= 16 and 3 * C <= _MFMA_MAX_WGRAD_CIN):
         return _MfmaDepthConv.apply(x2d, w2, D)
     x5 = x2d.view(B, D, C, H, W)

@@ -338,7 +338,7 @@ int mvster_conv_mfma_wgrad(const float *x, const float *dy, float *dweight, floa
  *   _fwd, input_gradient = 1 : pass x := dy, y := dx [N,C,H,W]: the layer's input gradient (bias ignored)
  *   _wgrad                   : dweight [Cout, 3*C, K, K]
  *   workspace: mvster_conv_mfma_workspace(N, 3*C, Cout, ...) (forward, weight gradient) / (N, 3*Cout, C, ...) (input gradient).
- *   3x3 layers with <= 8 output channels: _wgrad returns MVSTER_ERR_UNSUPPORTED. */
+ *   _wgrad: K = 3 and more than 8 output channels only, else MVSTER_ERR_UNSUPPORTED. */
 int mvster_conv_mfma_depth3_fwd(const float *x, const float *weight, const float *bias, float *y, float *workspace,
                                 long long workspace_floats, int N, int C, int Cout, int H, int W, int K, int depth,
                                 int input_gradient, mvster_stream_t stream);

@@ -23,7 +23,8 @@ CASES = [  # N, Cin, Cout, H, W, K, stride, bias
     (2, 32, 32, 37, 53, 3, 1, False), (1, 64, 64, 18, 40, 3, 1, False), (2, 16, 16, 33, 70, 3, 1, True),
     (1, 48, 16, 24, 40, 3, 1, False), (1, 96, 32, 17, 33, 3, 1, False), (1, 192, 64, 9, 20, 3, 1, False),
     (2, 64, 32, 20, 31, 3, 1, False), (1, 64, 16, 40, 64, 3, 1, False), (3, 64, 64, 9, 13, 1, 1, False),
-    (1, 20, 40, 11, 35, 3, 1, True), (2, 8, 16, 32, 48, 3, 2, False), (1, 16, 32, 35, 67, 3, 2, False),
+    (1, 20, 40, 11, 35, 3, 1, True), (2, 64, 72, 21, 37, 1, 1, True), (1, 100, 33, 9, 40, 1, 1, False), (2, 16, 130, 8, 33, 1, 1, False),
+    (2, 8, 16, 32, 48, 3, 2, False), (1, 16, 32, 35, 67, 3, 2, False),
     (1, 32, 64, 24, 40, 3, 2, False), (2, 8, 16, 40, 64, 5, 2, False), (1, 16, 32, 33, 61, 5, 2, False),
     (1, 32, 64, 20, 36, 5, 2, True), (5, 32, 32, 16, 32, 3, 1, False),
     # <= 8 output channels, 3x3 stride 1: the weight gradient with the tap rows packed next to the output channels
