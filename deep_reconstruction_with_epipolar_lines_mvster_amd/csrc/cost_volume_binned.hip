@@ -22,114 +22,51 @@
 //   tile_owner_kernel<C,G,D>    one workgroup per tile as described above (C = 8: tile_owner_c8_kernel<G,D>)
 // The per-(view, pixel, hypothesis) group coefficients come from cost_volume_bwd_nhwc_kernel<..., DEFER = true>
 // (cost_volume_bwd.hip): tap gradient = coef[group(c)] * ref[c] * bilinear weight.
+#include <type_traits>
+
 #include "cost_volume_common.h"
 
 namespace mvster {
 
-// ------------------------------------------------------------------------------------------------ counting sort by tile
+// ------------------------------------------------------------------------------------------------ counting sort by bin
 struct BinArgs {
     const float* pose;      // [B,S,12]
     const float* hypo;      // [B,D,HW]
     VolumeDims dm;
     BinGrid bg;
-    int tiles_per_view, blocks_x;
+    int tiles_per_view, max_items;
 };
 
-constexpr int kViewBatch = 4;        // views whose tables are live together (their global atomics are in flight together)
-constexpr int kTableLog = 8;         // LDS hash table entries per view: 256 lanes x <= 4 tiles rarely exceed a few dozen keys
-constexpr int kTable = 1 << kTableLog;
-constexpr int kMaxProbes = 24;
-
-// A workgroup's samples of one view touch a handful of tiles.  Counting them one global atomic per lane runs at the
-// per-lane atomic rate (557 M adds = 8.6 ms at DTU stage 4, measured); aggregated per workgroup it is one request per
-// distinct tile.  table: open addressing, linear probing; a sample that finds no entry within kMaxProbes goes to memory
-// on its own (correct, just slow).
-// FILL = false: counters[tile] += n.  FILL = true: counters is the cursor array (starts at the tile's offset); the value
-// returned by the add is the first position of the workgroup's samples of that tile.
+// Stand-alone count (FILL = false) / fill (FILL = true) pass for a backward whose forward did not count: the same
+// projection and the same run aggregation as the fused passes (cost_volume_common.h), one lane per (pixel, hypothesis),
+// all views in turn.  FILL: `counters` is the cursor array (starts at the bin offsets).
 template <bool FILL, int D>
 __global__ void __launch_bounds__(kBlock)
 bin_items_kernel(BinArgs a, int* __restrict__ counters, int* __restrict__ items) {
-    constexpr int PXB = kBlock / D;                                // reference pixels per workgroup
-    constexpr int BWP = 8, BHP = PXB / BWP;                        // as an 8 x (8 | 4 | 2) block
-    __shared__ int keys[kViewBatch][kTable];
-    __shared__ int cnts[kViewBatch][kTable];
-    [[maybe_unused]] __shared__ int bases[kViewBatch][kTable];
+    constexpr int PXB = kBlock / D;
     const VolumeDims& dm = a.dm;
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    if (tile >= dm.ntiles) return;
     const int HW = dm.H * dm.W;
     const int b = blockIdx.y;
-    const int by = blockIdx.x / a.blocks_x, bx = blockIdx.x - by * a.blocks_x;
-    const int d = threadIdx.x % D, q = threadIdx.x / D;
-    const int xr = bx * BWP + q % BWP, yr = by * BHP + q / BWP;
-    const bool live = xr < dm.W && yr < dm.H;
-    const int x = min(xr, dm.W - 1), y = min(yr, dm.H - 1);
-    const int p = y * dm.W + x;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
-    const float hyp = a.hypo[((size_t)b * D + d) * HW + p];
-    const int item = p * D + d;
-
-    for (int s0 = 0; s0 < dm.S; s0 += kViewBatch) {
-        for (int e = threadIdx.x; e < kViewBatch * kTable; e += kBlock) {
-            (&keys[0][0])[e] = -1;
-            (&cnts[0][0])[e] = 0;
+    const int lane = threadIdx.x & 63;
+    const int d = threadIdx.x % D, pl = threadIdx.x / D;
+    const OwnedPixel own = owned_pixel<PXB>(tile, pl, dm.H, dm.W);
+    const float hyp = a.hypo[((size_t)b * D + d) * HW + own.p];
+    const LaneMasks lm = lane_masks(lane);
+    const int item = pack_item(own.x, own.y, d);
+    BinCount bc{counters, a.bg, a.tiles_per_view};
+    BinFill bf{counters, items, a.bg, a.tiles_per_view, a.max_items};
+    for (int s = 0; s < dm.S; ++s) {
+        const Pose q = load_pose(a.pose + ((size_t)b * dm.S + s) * 12);
+        const Landing l = land(q, rotate_pixel(q, (float)own.x, (float)own.y), hyp, dm.Hs, dm.Ws);
+        int* __restrict__ view = counters + ((size_t)b * dm.S + s) * a.tiles_per_view * kBinCats;
+        if constexpr (FILL) {
+            const Claim c = claim_slots<0>(bf, view, l, own.live, lane, lm);
+            consume_claim<0>(bf, c, lane, item);
+        } else {
+            count_sample<0>(bc, view, l, own.live, lane, lm);
         }
-        __syncthreads();
-        int where[kViewBatch][4];        // table entry of (view, tap); -1: nothing to emit; -2: table full, go direct
-        int rank[kViewBatch][4];
-        int tile[kViewBatch][4];
-#pragma unroll
-        for (int v = 0; v < kViewBatch; ++v) {
-            const int s = s0 + v;
-            const bool on = live && s < dm.S;
-            const Pose qv = load_pose(a.pose + ((size_t)b * dm.S + min(s, dm.S - 1)) * 12);
-            const Taps t = project_taps(qv, rotate_pixel(qv, (float)x, (float)y), hyp, dm.Hs, dm.Ws, half_w, half_h);
-            bool emit[4];
-            footprint_tiles(t, a.bg, tile[v], emit);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                where[v][k] = -1;
-                rank[v][k] = 0;
-                if (on && emit[k]) {
-                    unsigned h = ((unsigned)tile[v][k] * 0x9E3779B1u) >> (32 - kTableLog);
-                    int found = -2;
-                    for (int probe = 0; probe < kMaxProbes; ++probe) {
-                        const int old = atomicCAS(&keys[v][h], -1, tile[v][k]);
-                        if (old == -1 || old == tile[v][k]) {
-                            found = (int)h;
-                            break;
-                        }
-                        h = (h + 1) & (kTable - 1);
-                    }
-                    where[v][k] = found;
-                    if (found >= 0) rank[v][k] = atomicAdd(&cnts[v][found], 1);
-                }
-            }
-        }
-        __syncthreads();
-        // one global atomic per distinct (view, tile) of the workgroup
-        for (int e = threadIdx.x; e < kViewBatch * kTable; e += kBlock) {
-            const int n = (&cnts[0][0])[e];
-            if (n > 0) {
-                const int v = e >> kTableLog;
-                int* __restrict__ c = counters + ((size_t)b * dm.S + (s0 + v)) * a.tiles_per_view + (&keys[0][0])[e];
-                if constexpr (FILL) (&bases[0][0])[e] = atomicAdd(c, n);
-                else atomicAdd(c, n);
-            }
-        }
-        if constexpr (FILL) __syncthreads();
-#pragma unroll
-        for (int v = 0; v < kViewBatch; ++v) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (where[v][k] == -2) {                           // table full: on its own
-                    int* __restrict__ c = counters + ((size_t)b * dm.S + (s0 + v)) * a.tiles_per_view + tile[v][k];
-                    if constexpr (FILL) items[atomicAdd(c, 1)] = item;
-                    else atomicAdd(c, 1);
-                } else if (FILL && where[v][k] >= 0) {
-                    items[bases[v][where[v][k]] + rank[v][k]] = item;
-                }
-            }
-        }
-        __syncthreads();                                           // tables are cleared again next round
     }
 }
 
@@ -191,12 +128,12 @@ struct OwnerArgs {
     const float* ref;       // [B,HW,C]
     const float* pose;
     const float* hypo;
-    const int* offsets;     // [nbins + 1]
+    const int* offsets;     // [nbins + 1], nbins = ntiles * 4
     const int* items;
     GradPtrs gsrcs;
     VolumeDims dm;
     BinGrid bg;
-    int tiles_per_view, nbins;
+    int tiles_per_view, ntiles;          // ntiles = B * S * tiles_per_view workgroups
 };
 
 template <int C>
@@ -209,8 +146,49 @@ struct OwnerTile {
     static constexpr int CHUNK = NT * KPT;                         // 384 (48 B each in LDS) / 1536 / 1536 / 1024 samples (16 B each)
 };
 
+// The samples a tile's owner has to look at: its own four lists (interior, bottom row, right column, corner -- one
+// contiguous stretch of the item array, which the right-column and corner lists of the LEFT neighbour directly precede),
+// the bottom-row and corner lists of the tile above and the corner list of the upper-left tile.  Position i of the
+// concatenation is item i + shift(i).
+struct OwnerLists {
+    int n;                  // samples in all
+    int c0, c1, c2;         // cumulative ends of the first three stretches
+    int s0, d1, d2, d3;     // shift of the first stretch, shift increments of the following ones
+};
+__device__ __forceinline__ OwnerLists owner_lists(const int* __restrict__ offsets, int tile, int tx, int ty, int tiles_x) {
+    const int t4 = tile * kBinCats, u4 = t4 - tiles_x * kBinCats;
+    const int a_beg = offsets[tx > 0 ? t4 - 2 : t4], a_end = offsets[t4 + 4];
+    int b_beg = 0, b_end = 0, c_beg = 0, c_end = 0, d_beg = 0, d_end = 0;
+    if (ty > 0) {
+        c_beg = offsets[u4 + 1];            // above: bottom row
+        c_end = offsets[u4 + 2];
+        d_beg = offsets[u4 + 3];            // above: corner
+        d_end = offsets[u4 + 4];
+        if (tx > 0) {
+            b_beg = offsets[u4 - 1];        // upper left: corner
+            b_end = offsets[u4];
+        }
+    }
+    OwnerLists o;
+    o.c0 = a_end - a_beg;
+    o.c1 = o.c0 + (b_end - b_beg);
+    o.c2 = o.c1 + (c_end - c_beg);
+    o.n = o.c2 + (d_end - d_beg);
+    const int s1 = b_beg - o.c0, s2 = c_beg - o.c1, s3 = d_beg - o.c2;
+    o.s0 = a_beg;
+    o.d1 = s1 - a_beg;
+    o.d2 = s2 - s1;
+    o.d3 = s3 - s2;
+    return o;
+}
+// (written with arithmetic on the comparison results: a chain of selects on four values becomes a lookup table in scratch)
+__device__ __forceinline__ int owner_item(const int* __restrict__ items, const OwnerLists& o, int i) {
+    const int shift = o.s0 + (i >= o.c0 ? o.d1 : 0) + (i >= o.c1 ? o.d2 : 0) + (i >= o.c2 ? o.d3 : 0);
+    return items[i + shift];
+}
+
 struct __attribute__((aligned(16))) SampleRec {
-    int id;                 // p * D + d
+    int id;                 // packed item: reference pixel and hypothesis
     int mask;               // in-map bits of the four taps
     float fx, fy;           // fractional sample position
 };
@@ -231,7 +209,7 @@ tile_owner_kernel(OwnerArgs a) {
     __shared__ __attribute__((aligned(16))) float out[TH * TW * C];
 
     const int bin = xcd_contiguous_tile(blockIdx.x, gridDim.x);
-    if (bin >= a.nbins) return;
+    if (bin >= a.ntiles) return;
     const VolumeDims& dm = a.dm;
     const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
     const int tv = bin % a.tiles_per_view, bs = bin / a.tiles_per_view;
@@ -245,8 +223,8 @@ tile_owner_kernel(OwnerArgs a) {
 
     for (int i = tid; i < TH * TW * C; i += NT) out[i] = 0.0f;
 
-    const int beg = a.offsets[bin], n = a.offsets[bin + 1] - beg;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+    const OwnerLists lists = owner_lists(a.offsets, bin, tx, ty, a.bg.tiles_x);
+    const int n = lists.n;
     const Pose q = load_pose(a.pose + ((size_t)b * dm.S + s) * 12);
     const float* __restrict__ hypo = a.hypo + (size_t)b * D * HW;
     const float* __restrict__ dcor = a.dcor + ((size_t)b * dm.S + s) * HW * D * G;
@@ -264,17 +242,17 @@ tile_owner_kernel(OwnerArgs a) {
             const int i = tid + j * NT;
             cell[j] = -1;
             if (i < m) {
-                const int id = a.items[beg + c0 + i];
-                const int p = id / D, d = id - p * D;
-                const int y = p / dm.W, x = p - y * dm.W;
-                const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hypo[(size_t)d * HW + p], dm.Hs, dm.Ws,
-                                            half_w, half_h);
-                const int cx = t.ix - x0 + 1, cy = t.iy - y0 + 1;
-                rec[j].id = id;
-                rec[j].mask = t.mask;
-                rec[j].fx = t.fx;
-                rec[j].fy = t.fy;
-                if ((unsigned)cx < (unsigned)BW && (unsigned)cy < (unsigned)T::BH) {     // always, for a sample of this tile
+                const int id = owner_item(a.items, lists, c0 + i);
+                int x, y, d;
+                unpack_item(id, x, y, d);
+                const int p = __mul24(y, dm.W) + x;
+                const Landing l = land(q, rotate_pixel(q, (float)x, (float)y), hypo[(size_t)d * HW + p], dm.Hs, dm.Ws);
+                const int cx = l.ix - x0 + 1, cy = l.iy - y0 + 1;
+                rec[j].id = p * D + d;
+                rec[j].mask = landing_mask(l);
+                rec[j].fx = l.fx;
+                rec[j].fy = l.fy;
+                if ((unsigned)cx < (unsigned)BW && (unsigned)cy < (unsigned)T::BH) {     // always, for a sample listed here
                     cell[j] = cy * BW + cx;
                     slot[j] = atomicAdd(&cnt[cell[j]], 1);
                 }
@@ -402,16 +380,14 @@ tile_owner_kernel(OwnerArgs a) {
 }
 
 // ---- C = 8: the same ownership scheme with everything a sample contributes staged in LDS ---------------------------------
-// At eight channels the stage has the most samples (DTU stage 4: 139 M per backward) and the least arithmetic per
+// At eight channels the stage has the most samples (DTU stage 4: 121 M per backward) and the least arithmetic per
 // sample; walking them with one gather per step (kernel above) is bound by the latency of those gathers (3.9 ms).
 // Here the sorting pass -- one lane per SAMPLE, all lanes busy, neighbouring lanes = the hypotheses of one pixel, so
 // their coefficient and reference loads share lines -- also fetches the coefficients and the reference feature and
-// leaves the finished per-channel gradient coef[group(c)] * ref[c] in the sample's LDS record (48 bytes).  The owners'
-// walk then touches LDS only.
+// leaves the finished per-channel gradient coef[group(c)] * ref[c] and the four bilinear weights in the sample's LDS record
+// (48 bytes).  The owners' walk then touches LDS only: three 16-byte reads and 16 packed FMAs per sample.
 struct __attribute__((aligned(16))) StagedRec {
-    int mask;               // in-map bits of the four taps
-    float fx, fy;           // fractional sample position
-    int pad;
+    float w[4];             // bilinear weights, 0 for a tap outside the map
     float dw[8];            // coef[group(c)] * ref[c]
 };
 
@@ -428,7 +404,7 @@ tile_owner_c8_kernel(OwnerArgs a) {
     __shared__ __attribute__((aligned(16))) float out[TH * TW * C];
 
     const int bin = xcd_contiguous_tile(blockIdx.x, gridDim.x);
-    if (bin >= a.nbins) return;
+    if (bin >= a.ntiles) return;
     const VolumeDims& dm = a.dm;
     const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
     const int tv = bin % a.tiles_per_view, bs = bin / a.tiles_per_view;
@@ -441,48 +417,44 @@ tile_owner_c8_kernel(OwnerArgs a) {
 
     for (int i = tid; i < TH * TW * C; i += NT) out[i] = 0.0f;
 
-    const int beg = a.offsets[bin], n = a.offsets[bin + 1] - beg;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+    const OwnerLists lists = owner_lists(a.offsets, bin, tx, ty, a.bg.tiles_x);
+    const int n = lists.n;
     const Pose q = load_pose(a.pose + ((size_t)b * dm.S + s) * 12);
     const float* __restrict__ hypo = a.hypo + (size_t)b * D * HW;
     const float* __restrict__ dcor = a.dcor + ((size_t)b * dm.S + s) * HW * D * G;
     const float* __restrict__ ref = a.ref + (size_t)b * HW * C;
 
-    float acc[4][C];
+    f32x2 acc[4][C / 2];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[k][c] = 0.0f;
+        for (int c = 0; c < C / 2; ++c) acc[k][c] = f32x2{0.0f, 0.0f};
 
-    // the item ids of the NEXT chunk are requested while this chunk's data is in flight: one dependent round trip per
+    // the items of the NEXT chunk are requested while this chunk's data is in flight: one dependent round trip per
     // chunk instead of two
     int id_next[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const int i = tid + j * NT;
-        id_next[j] = i < n ? a.items[beg + i] : -1;
+        id_next[j] = i < n ? owner_item(a.items, lists, i) : -1;
     }
     for (int c0 = 0; c0 < n; c0 += CHUNK) {
         cnt[tid] = 0;
         __syncthreads();
-        // ---- fetch: everything that depends on the ids, all in flight together -----------------------------------------
-        int id[KPT];
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) id[j] = id_next[j];
-        float hyp[KPT], cf[KPT][G];
-        float4 r0[KPT], r1[KPT];
+        // ---- fetch: everything that depends on the items, all in flight together ---------------------------------------
+        int id[KPT], px[KPT], py[KPT];
+        float hyp[KPT];
+        float4 cf0[KPT], cf1[KPT], r0[KPT], r1[KPT];
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
-            const int idj = max(id[j], 0);
-            const int p = idj / D, d = idj - p * D;
+            id[j] = id_next[j];
+            int d;
+            unpack_item(max(id[j], 0), px[j], py[j], d);
+            const int p = __mul24(py[j], dm.W) + px[j];
             hyp[j] = hypo[(size_t)d * HW + p];
-            const float4* __restrict__ cp = reinterpret_cast<const float4*>(dcor + (size_t)idj * G);
-            const float4 a0 = cp[0];
-            cf[j][0] = a0.x; cf[j][1] = a0.y; cf[j][2] = a0.z; cf[j][3] = a0.w;
-            if constexpr (G == 8) {
-                const float4 a1 = cp[1];
-                cf[j][4] = a1.x; cf[j][5] = a1.y; cf[j][6] = a1.z; cf[j][7] = a1.w;
-            }
+            const float4* __restrict__ cp = reinterpret_cast<const float4*>(dcor + ((size_t)p * D + d) * G);
+            cf0[j] = cp[0];
+            if constexpr (G == 8) cf1[j] = cp[1];
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(ref + (size_t)p * C);
             r0[j] = rp[0];
             r1[j] = rp[1];
@@ -490,7 +462,7 @@ tile_owner_c8_kernel(OwnerArgs a) {
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const int i = c0 + CHUNK + tid + j * NT;
-            id_next[j] = i < n ? a.items[beg + i] : -1;
+            id_next[j] = i < n ? owner_item(a.items, lists, i) : -1;
         }
         // ---- project, count per owner ----------------------------------------------------------------------------------
         StagedRec rec[KPT];
@@ -499,17 +471,14 @@ tile_owner_c8_kernel(OwnerArgs a) {
         for (int j = 0; j < KPT; ++j) {
             cell[j] = -1;
             if (id[j] >= 0) {
-                const int p = id[j] / D;
-                const int y = p / dm.W, x = p - y * dm.W;
-                const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hyp[j], dm.Hs, dm.Ws, half_w, half_h);
-                const int cx = t.ix - x0 + 1, cy = t.iy - y0 + 1;
-                rec[j].mask = t.mask;
-                rec[j].fx = t.fx;
-                rec[j].fy = t.fy;
-                rec[j].pad = 0;
+                const Landing l = land(q, rotate_pixel(q, (float)px[j], (float)py[j]), hyp[j], dm.Hs, dm.Ws);
+                const int cx = l.ix - x0 + 1, cy = l.iy - y0 + 1;
+                weights_from_fraction(l.fx, l.fy, landing_mask(l), rec[j].w);
                 const float rv[C] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w, r1[j].x, r1[j].y, r1[j].z, r1[j].w};
+                const float cf[8] = {cf0[j].x, cf0[j].y, cf0[j].z, cf0[j].w, G == 8 ? cf1[j].x : 0.0f, G == 8 ? cf1[j].y : 0.0f,
+                                     G == 8 ? cf1[j].z : 0.0f, G == 8 ? cf1[j].w : 0.0f};
 #pragma unroll
-                for (int c = 0; c < C; ++c) rec[j].dw[c] = cf[j][c / CPG] * rv[c];
+                for (int c = 0; c < C; ++c) rec[j].dw[c] = cf[c / CPG] * rv[c];
                 if ((unsigned)cx < (unsigned)BW && (unsigned)cy < (unsigned)T::BH) {
                     cell[j] = cy * BW + cx;
                     slot[j] = atomicAdd(&cnt[cell[j]], 1);
@@ -547,13 +516,16 @@ tile_owner_c8_kernel(OwnerArgs a) {
         // ---- walk: LDS only ------------------------------------------------------------------------------------------------
         const int mine = owner ? cnt[tid] : 0, first = owner ? start[tid] : 0;
         for (int k = 0; k < mine; ++k) {
-            const StagedRec r = sorted[first + k];
-            float w[4];
-            weights_from_fraction(r.fx, r.fy, r.mask, w);
+            const float4* __restrict__ rp = reinterpret_cast<const float4*>(&sorted[first + k]);
+            const float4 w = rp[0], d0 = rp[1], d1 = rp[2];
+            const f32x2 dv[4] = {{d0.x, d0.y}, {d0.z, d0.w}, {d1.x, d1.y}, {d1.z, d1.w}};
+            const float wk[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int c = 0; c < C; ++c)
+            for (int kk = 0; kk < 4; ++kk) {
+                const f32x2 ww = {wk[kk], wk[kk]};
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc[kk][c] = fmaf(r.dw[c], w[kk], acc[kk][c]);
+                for (int c = 0; c < C / 2; ++c) acc[kk][c] = __builtin_elementwise_fma(dv[c], ww, acc[kk][c]);
+            }
         }
         __syncthreads();                                           // `sorted`, `cnt`, `start` are rewritten by the next chunk
     }
@@ -566,8 +538,8 @@ tile_owner_c8_kernel(OwnerArgs a) {
         if (owner && (unsigned)lx < (unsigned)TW && (unsigned)ly < (unsigned)TH) {
             float4* __restrict__ o = reinterpret_cast<float4*>(&out[(ly * TW + lx) * C]);
             float4 u = o[0], v = o[1];
-            u.x += acc[kk][0]; u.y += acc[kk][1]; u.z += acc[kk][2]; u.w += acc[kk][3];
-            v.x += acc[kk][4]; v.y += acc[kk][5]; v.z += acc[kk][6]; v.w += acc[kk][7];
+            u.x += acc[kk][0].x; u.y += acc[kk][0].y; u.z += acc[kk][1].x; u.w += acc[kk][1].y;
+            v.x += acc[kk][2].x; v.y += acc[kk][2].y; v.z += acc[kk][3].x; v.w += acc[kk][3].y;
             o[0] = u;
             o[1] = v;
         }
@@ -594,7 +566,7 @@ tile_owner_c8_kernel(OwnerArgs a) {
 
 template <int C, int G>
 static int launch_owner(const OwnerArgs& a, int D, hipStream_t st) {
-    const dim3 grid((unsigned)(((a.nbins + 7) / 8) * 8)), block(OwnerTile<C>::NT);
+    const dim3 grid((unsigned)(((a.ntiles + 7) / 8) * 8)), block(OwnerTile<C>::NT);
     if constexpr (C == 8) {
         if (D == 4) hipLaunchKernelGGL((tile_owner_c8_kernel<G, 4>), grid, block, 0, st, a);
         else if (D == 8) hipLaunchKernelGGL((tile_owner_c8_kernel<G, 8>), grid, block, 0, st, a);
@@ -611,14 +583,16 @@ static int launch_owner(const OwnerArgs& a, int D, hipStream_t st) {
 
 template <bool FILL>
 static int launch_bin_items(const BinArgs& ba, int B, int D, int* counters, int* items, hipStream_t st) {
-    const VolumeDims& dm = ba.dm;
     BinArgs a = ba;
-    const int bhp = kBlock / D / 8;
-    a.blocks_x = (dm.W + 7) / 8;
-    const dim3 grid((unsigned)(a.blocks_x * ((dm.H + bhp - 1) / bhp)), (unsigned)B);
-    if (D == 4) hipLaunchKernelGGL((bin_items_kernel<FILL, 4>), grid, dim3(kBlock), 0, st, a, counters, items);
-    else if (D == 8) hipLaunchKernelGGL((bin_items_kernel<FILL, 8>), grid, dim3(kBlock), 0, st, a, counters, items);
-    else if (D == 16) hipLaunchKernelGGL((bin_items_kernel<FILL, 16>), grid, dim3(kBlock), 0, st, a, counters, items);
+    auto launch = [&](auto dtag) {
+        constexpr int DD = decltype(dtag)::value;
+        a.dm.ntiles = PixelBlocks<kBlock / DD>::tiles(a.dm.H, a.dm.W);
+        const dim3 grid((unsigned)(((a.dm.ntiles + 7) / 8) * 8), (unsigned)B);
+        hipLaunchKernelGGL((bin_items_kernel<FILL, DD>), grid, dim3(kBlock), 0, st, a, counters, items);
+    };
+    if (D == 4) launch(std::integral_constant<int, 4>{});
+    else if (D == 8) launch(std::integral_constant<int, 8>{});
+    else if (D == 16) launch(std::integral_constant<int, 16>{});
     else return MVSTER_ERR_UNSUPPORTED;
     return launch_status();
 }
@@ -648,12 +622,12 @@ int launch_binned_scatter(const float* ref, const float* pose, const float* hypo
             (void)hipGetLastError();
             return MVSTER_ERR_LAUNCH;
         }
-        BinArgs ba{pose, hypo, dm, bg, bg.tiles_x * bg.tiles_y, 0};
+        BinArgs ba{pose, hypo, dm, bg, bg.tiles_x * bg.tiles_y, (int)lay.max_items};
         if (int rc = launch_bin_items<false>(ba, B, D, counts, nullptr, st)) return rc;
         if (int rc = launch_bin_scan(counts, workspace, lay, st)) return rc;
         if (int rc = launch_bin_items<true>(ba, B, D, cursor, items, st)) return rc;
     }
-    OwnerArgs oa{workspace + lay.coef, ref, pose, hypo, offsets, items, gsrcs, dm, bg, bg.tiles_x * bg.tiles_y, nbins};
+    OwnerArgs oa{workspace + lay.coef, ref, pose, hypo, offsets, items, gsrcs, dm, bg, bg.tiles_x * bg.tiles_y, nbins / kBinCats};
 #define X(C_, G_) \
     if (C == C_ && G == G_) return launch_owner<C_, G_>(oa, D, st);
     X(8, 4) X(16, 4) X(32, 4) X(64, 4) X(8, 8) X(16, 8) X(32, 8) X(64, 8)

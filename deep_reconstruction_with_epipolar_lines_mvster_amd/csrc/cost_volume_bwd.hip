@@ -32,8 +32,7 @@ cost_volume_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__
     const int p = live ? praw : HW - 1;
     const int y = p / dm.W, x = p - y * dm.W;
     const float fx = (float)x, fy = (float)y;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
-    const float inv_tc = 1.0f / (dm.temp * dm.sqrt_c);
+    const float inv_tc = dm.inv_tc;
 
     const float* __restrict__ refp = ref + (size_t)b * C * HW + p;
     float hyp[DPL], gd[G][DPL], godot[DPL];
@@ -41,7 +40,7 @@ cost_volume_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__
     for (int j = 0; j < DPL; ++j) {
         const int d = dl * DPL + j;
         hyp[j] = hypo[((size_t)b * D + d) * HW + p];
-        const float rden = 1.0f / wsum[((size_t)b * D + d) * HW + p];
+        const float rden = div_fast(1.0f, wsum[((size_t)b * D + d) * HW + p]);
         godot[j] = 0.0f;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -64,17 +63,21 @@ cost_volume_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__
         float warped[C][DPL], cor[G][DPL];
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
-            taps[j] = project_taps(q, ray, hyp[j], dm.Hs, dm.Ws, half_w, half_h);
+            taps[j] = project_taps(q, ray, hyp[j], dm.Hs, dm.Ws);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                float acc = 0.0f;
+                float ax = 0.0f, ay = 0.0f;                  // same association as gather_correlate() (channels-last kernels)
 #pragma unroll
                 for (int k = 0; k < CPG; ++k) {
                     const int c = g * CPG + k;
                     warped[c][j] = sample(srcb + (size_t)c * HWs, taps[j]);
-                    acc = fmaf(warped[c][j], refp[(size_t)c * HW], acc);
+                    const float r = refp[(size_t)c * HW] * (1.0f / CPG);
+                    if (k == 0) ax = warped[c][j] * r;
+                    else if (k == 1) ay = warped[c][j] * r;
+                    else if (k % 2 == 0) ax = fmaf(warped[c][j], r, ax);
+                    else ay = fmaf(warped[c][j], r, ay);
                 }
-                cor[g][j] = acc * (1.0f / CPG);
+                cor[g][j] = CPG == 1 ? ax : ax + ay;
             }
         }
         float a[DPL], m = -INFINITY;
@@ -90,14 +93,14 @@ cost_volume_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__
         float e[DPL], sum = 0.0f;
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
-            e[j] = expf(a[j] - m);
+            e[j] = exp_nonpos(a[j] - m);
             sum += e[j];
         }
         sum = group_sum<DL>(sum);
         float what[DPL], dw[DPL], sdot = 0.0f;
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
-            what[j] = e[j] / sum;
+            what[j] = div_fast(e[j], sum);
             float acc = -godot[j];
 #pragma unroll
             for (int g = 0; g < G; ++g) acc = fmaf(gd[g][j], cor[g][j], acc);
@@ -108,7 +111,7 @@ cost_volume_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
             const float da = what[j] * (dw[j] - sdot) * inv_tc;
-            const float w = what[j] / dm.sqrt_c;
+            const float w = div_sqrt_c(what[j], dm);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const float dcor = fmaf(gd[g][j], w, da) * (1.0f / CPG);
@@ -278,193 +281,219 @@ __device__ __forceinline__ void split_window_flush(float (*strip)[Window<C / HS>
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ------------------------------------------------------------------------------- backward, channels-last features
-// DEFER: the source-feature gradient is NOT scattered here.  The kernel stores, per (view, pixel, hypothesis), the G
-// group coefficients dcor (gradient w.r.t. the warped feature = dcor[group(c)] * ref[c]) into `dcor_out`
-// [B,S,HW,D,G]; tile_scatter_kernel (cost_volume_scatter.hip) recomputes the taps and does the scatter with a
-// wave-private write-combining cache in LDS.
-template <int C, int G, int D, int DPL, bool DEFER = false>
+// ------------------------------------------------------------------------------- backward, channels-last features: dense atomics
+// Fallback route without workspace (MVSTER_BWD_ROUTE_DENSE): one lane per (pixel, hypothesis), the source-feature
+// gradient leaves through dense_scatter().
+template <int C, int G, int D, int DPL>
 __global__ void __launch_bounds__(kBlock)
 cost_volume_bwd_nhwc_kernel(const float* __restrict__ gvol, const float* __restrict__ vol,
                             const float* __restrict__ wsum, const float* __restrict__ ref, SrcPtrs srcs,
                             const float* __restrict__ pose, const float* __restrict__ hypo, float* __restrict__ gref,
-                            GradPtrs gsrcs, VolumeDims dm, float* __restrict__ dcor_out, BinFill bf) {
+                            GradPtrs gsrcs, VolumeDims dm) {
     constexpr int CPG = C / G;
-    constexpr int C4 = C / 4;
-    constexpr int DL = D / DPL;
-    constexpr int PXB = kBlock / DL;
+    constexpr int PXB = kBlock / D;
     static_assert(DPL == 1, "channels-last: one lane per (pixel, hypothesis); D = 4 with C <= 16 runs the split kernel below");
-    constexpr int kRow = kStageRow;
-    __shared__ __attribute__((aligned(16))) float stage[DEFER ? 1 : kBlock / kWave][DEFER ? 1 : kWave][kRow];   // wave-private strips
+    __shared__ __attribute__((aligned(16))) float stage[kBlock / kWave][kWave][kStageRow];   // wave-private strips
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     if (tile >= dm.ntiles) return;
     const int b = blockIdx.y;
     const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
-    const int dl = threadIdx.x % DL, pl = threadIdx.x / DL;
+    const int lane = threadIdx.x & 63;
+    const int d = threadIdx.x % D, pl = threadIdx.x / D;
     const OwnedPixel own = owned_pixel<PXB>(tile, pl, dm.H, dm.W);
     const bool live = own.live;
-    const int p = own.p, y = own.y, x = own.x;
-    const float fx = (float)x, fy = (float)y;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
-    const float inv_tc = 1.0f / (dm.temp * dm.sqrt_c);
+    const int p = own.p;
+    const float fx = (float)own.x, fy = (float)own.y;
 
-    const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C);
-    float hyp[DPL], gd[G][DPL], godot[DPL];
+    f32x2 ref2[C / 2];
+    float refv[C];
+    {
+        const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C);
 #pragma unroll
-    for (int j = 0; j < DPL; ++j) {
-        const int d = dl * DPL + j;
-        hyp[j] = hypo[((size_t)b * D + d) * HW + p];
-        const float rden = 1.0f / wsum[((size_t)b * D + d) * HW + p];
-        godot[j] = 0.0f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const size_t at = (((size_t)b * G + g) * D + d) * HW + p;
-            gd[g][j] = live ? gvol[at] * rden : 0.0f;
-            godot[j] = fmaf(gd[g][j], vol[at], godot[j]);
+        for (int i = 0; i < C / 4; ++i) {
+            const float4 r = refp[i];
+            refv[4 * i] = r.x; refv[4 * i + 1] = r.y; refv[4 * i + 2] = r.z; refv[4 * i + 3] = r.w;
+            ref2[2 * i] = f32x2{r.x, r.y} * (1.0f / CPG);
+            ref2[2 * i + 1] = f32x2{r.z, r.w} * (1.0f / CPG);
         }
+    }
+    const float hyp = hypo[((size_t)b * D + d) * HW + p];
+    const float rden = div_fast(1.0f, wsum[((size_t)b * D + d) * HW + p]);
+    float gd[G], godot = 0.0f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const size_t at = (((size_t)b * G + g) * D + d) * HW + p;
+        gd[g] = live ? gvol[at] * rden : 0.0f;            // a padding lane must contribute nothing to the atomics below
+        godot = fmaf(gd[g], vol[at], godot);
     }
     float dref[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) dref[c] = 0.0f;
 
-    // DEFER with bf.cursor: second pass of the counting sort (see BinFill).  The slots a view's samples claim with a
-    // returning atomic are consumed one view later, so that the atomic's round trip hides behind the next view's gathers.
-    [[maybe_unused]] int claim_leader[4] = {-1, -1, -1, -1}, claim_rank[4] = {0, 0, 0, 0}, claim_base[4] = {0, 0, 0, 0};
-    [[maybe_unused]] auto write_claimed_items = [&]() {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (__ballot(claim_leader[k] >= 0) == 0) continue;                      // wave-uniform
-            const int base = __shfl(claim_base[k], max(claim_leader[k], 0), kWave);
-            if (claim_leader[k] >= 0) bf.items[base + claim_rank[k]] = p * D + dl;
-        }
-    };
     for (int s = 0; s < dm.S; ++s) {
         const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C;
         float* __restrict__ gsrcb = gsrcs.p[s] + (size_t)b * HWs * C;
         const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
-        const Ray ray = rotate_pixel(q, fx, fy);
-        Taps taps[DPL];
-        float warped[C][DPL], cor[G][DPL];
+        const Landing l = land(q, rotate_pixel(q, fx, fy), hyp, dm.Hs, dm.Ws);
+        const Taps t = taps_of(l, dm.Hs, dm.Ws);
+        unsigned o[4];
+        float w4[4];
+        tap_addresses<C>(l, dm.Hs, dm.Ws, o, w4);
+        float cor[G];
+        f32x2 warped[C / 2];
+        gather_correlate<C, CPG, true>(srcb, o, w4, ref2, cor, warped);
+        float sg = cor[0];
 #pragma unroll
-        for (int j = 0; j < DPL; ++j) {
-            taps[j] = project_taps(q, ray, hyp[j], dm.Hs, dm.Ws, half_w, half_h);
-            const Taps& t = taps[j];
-            const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
-            const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
-            const float4* __restrict__ p10 = reinterpret_cast<const float4*>(srcb + (size_t)t.o10 * C);
-            const float4* __restrict__ p11 = reinterpret_cast<const float4*>(srcb + (size_t)t.o11 * C);
-            float cg[G];
+        for (int g = 1; g < G; ++g) sg += cor[g];
+        const float a = div_temp(sg, dm);
+        const float m = group_max<D>(a);
+        const float e = exp_nonpos(a - m);
+        const float what = div_fast(e, group_sum<D>(e));
+        float dw = -godot;
 #pragma unroll
-            for (int g = 0; g < G; ++g) cg[g] = 0.0f;
+        for (int g = 0; g < G; ++g) dw = fmaf(gd[g], cor[g], dw);
+        const float sdot = group_sum<D>(what * dw);
+        const float da = what * (dw - sdot) * dm.inv_tc;
+        const float w = div_sqrt_c(what, dm);
+        float dwarp[C];
 #pragma unroll
-            for (int c4 = 0; c4 < C4; ++c4) {
-                const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
-                const float4 r = refp[c4];
-                warped[4 * c4 + 0][j] = fmaf(dq.x, t.w11, fmaf(cq.x, t.w10, fmaf(bq.x, t.w01, a.x * t.w00)));
-                warped[4 * c4 + 1][j] = fmaf(dq.y, t.w11, fmaf(cq.y, t.w10, fmaf(bq.y, t.w01, a.y * t.w00)));
-                warped[4 * c4 + 2][j] = fmaf(dq.z, t.w11, fmaf(cq.z, t.w10, fmaf(bq.z, t.w01, a.z * t.w00)));
-                warped[4 * c4 + 3][j] = fmaf(dq.w, t.w11, fmaf(cq.w, t.w10, fmaf(bq.w, t.w01, a.w * t.w00)));
-                cg[(4 * c4 + 0) / CPG] = fmaf(warped[4 * c4 + 0][j], r.x, cg[(4 * c4 + 0) / CPG]);
-                cg[(4 * c4 + 1) / CPG] = fmaf(warped[4 * c4 + 1][j], r.y, cg[(4 * c4 + 1) / CPG]);
-                cg[(4 * c4 + 2) / CPG] = fmaf(warped[4 * c4 + 2][j], r.z, cg[(4 * c4 + 2) / CPG]);
-                cg[(4 * c4 + 3) / CPG] = fmaf(warped[4 * c4 + 3][j], r.w, cg[(4 * c4 + 3) / CPG]);
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) cor[g][j] = cg[g] * (1.0f / CPG);
+        for (int c = 0; c < C; ++c) {
+            const float dcor = fmaf(gd[c / CPG], w, da) * (1.0f / CPG);
+            dref[c] = fmaf(dcor, c % 2 == 0 ? warped[c / 2].x : warped[c / 2].y, dref[c]);
+            dwarp[c] = dcor * refv[c];
         }
-        float a[DPL], m = -INFINITY;
+        dense_scatter<C>(stage[threadIdx.x >> 6], lane, t, dwarp, gsrcb, live);
+    }
+    float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C);
 #pragma unroll
-        for (int j = 0; j < DPL; ++j) {
-            float sg = cor[0][j];
+    for (int c4 = 0; c4 < C / 4; ++c4) {
+        float4 v;
+        v.x = group_sum<D>(dref[4 * c4 + 0]);
+        v.y = group_sum<D>(dref[4 * c4 + 1]);
+        v.z = group_sum<D>(dref[4 * c4 + 2]);
+        v.w = group_sum<D>(dref[4 * c4 + 3]);
+        if (live && d == 0) grefp[c4] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------- coefficient kernel (deferred routes), C <= 16
+// First half of the binned / tiled-scatter routes: everything that needs the feature gathers -- per-view correlations,
+// softmax, the reference gradient (each lane owns its pixel: plain stores) -- and, per (view, pixel, hypothesis), the G
+// group coefficients dcor (gradient w.r.t. the warped feature = dcor[group(c)] * ref[c]) into `dcor_out` [B,S,HW,D,G];
+// the source-feature gradient is formed by the owner kernels of cost_volume_binned.hip (or tile_scatter_kernel) from
+// them.  With bf.cursor the kernel also takes the FILL pass of the counting sort: the head of each run of equal bins
+// claims the run's slots with one returning atomic, consumed one view later so that the atomic's round trip hides behind
+// the next view's gathers.
+// Round 3: ~170 VALU instructions per (sample, view) instead of ~500 (same measures as the forward kernel).
+template <int C, int G, int D>
+__global__ void __launch_bounds__(kBlock)
+cost_volume_bwd_coef_kernel(const float* __restrict__ gvol, const float* __restrict__ vol,
+                            const float* __restrict__ wsum, const float* __restrict__ ref, SrcPtrs srcs,
+                            const float* __restrict__ pose, const float* __restrict__ hypo, float* __restrict__ gref,
+                            VolumeDims dm, float* __restrict__ dcor_out, BinFill bf) {
+    static_assert(C <= 16, "C >= 32 runs cost_volume_bwd_coef_split_kernel");
+    constexpr int CPG = C / G;
+    constexpr int PXB = kBlock / D;
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    if (tile >= dm.ntiles) return;
+    const int b = blockIdx.y;
+    const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
+    const int lane = threadIdx.x & 63;
+    const int d = threadIdx.x % D, pl = threadIdx.x / D;
+    const OwnedPixel own = owned_pixel<PXB>(tile, pl, dm.H, dm.W);
+    const bool live = own.live;
+    const int p = own.p;
+    const float fx = (float)own.x, fy = (float)own.y;
+
+    f32x2 ref2[C / 2];
+    {
+        const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C);
 #pragma unroll
-            for (int g = 1; g < G; ++g) sg += cor[g][j];
-            a[j] = div_temp(sg, dm);
-            m = fmaxf(m, a[j]);
-        }
-        m = group_max<DL>(m);
-        float e[DPL], sum = 0.0f;
-#pragma unroll
-        for (int j = 0; j < DPL; ++j) {
-            e[j] = expf(a[j] - m);
-            sum += e[j];
-        }
-        sum = group_sum<DL>(sum);
-        float what[DPL], dw[DPL], sdot = 0.0f;
-#pragma unroll
-        for (int j = 0; j < DPL; ++j) {
-            what[j] = e[j] / sum;
-            float acc = -godot[j];
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc = fmaf(gd[g][j], cor[g][j], acc);
-            dw[j] = acc;
-            sdot = fmaf(what[j], dw[j], sdot);
-        }
-        sdot = group_sum<DL>(sdot);
-        const int lane = threadIdx.x & 63;
-#pragma unroll
-        for (int j = 0; j < DPL; ++j) {
-            const float da = what[j] * (dw[j] - sdot) * inv_tc;
-            const float w = what[j] / dm.sqrt_c;
-            float dwarp[C];
-#pragma unroll
-            for (int c4 = 0; c4 < C4; ++c4) {
-                const float4 r = refp[c4];
-                const float rr[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = 4 * c4 + i;
-                    const float dcor = fmaf(gd[c / CPG][j], w, da) * (1.0f / CPG);
-                    dref[c] = fmaf(dcor, warped[c][j], dref[c]);
-                    dwarp[c] = dcor * rr[i];
-                }
-            }
-            if constexpr (DEFER) {
-                if (live) {
-                    float* __restrict__ out = dcor_out + ((((size_t)b * dm.S + s) * HW + p) * D + (dl * DPL + j)) * G;
-#pragma unroll
-                    for (int g4 = 0; g4 < G / 4; ++g4)
-                        reinterpret_cast<float4*>(out)[g4] =
-                            make_float4(fmaf(gd[4 * g4 + 0][j], w, da) * (1.0f / CPG), fmaf(gd[4 * g4 + 1][j], w, da) * (1.0f / CPG),
-                                        fmaf(gd[4 * g4 + 2][j], w, da) * (1.0f / CPG), fmaf(gd[4 * g4 + 3][j], w, da) * (1.0f / CPG));
-                }
-            } else {
-                dense_scatter<C>(stage[threadIdx.x >> 6], lane, taps[j], dwarp, gsrcb, live);
-            }
-        }
-        if constexpr (DEFER) {
-            if (bf.cursor != nullptr) {                                              // wave-uniform
-                write_claimed_items();                                               // the previous view's
-                int id[4];
-                bool emit[4];
-                footprint_tiles(taps[0], bf.bg, id, emit);
-                int* __restrict__ cur = bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view;
-                const bool straddles = __ballot(live && (emit[1] | emit[2] | emit[3])) != 0;     // wave-uniform
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (k > 0 && !straddles) {
-                        claim_leader[k] = -1;
-                        continue;
-                    }
-                    int count;
-                    wave_group(id[k], live && emit[k], lane, claim_leader[k], claim_rank[k], count);
-                    claim_base[k] = lane == claim_leader[k] ? atomicAdd(cur + id[k], count) : 0;
-                }
-            }
+        for (int i = 0; i < C / 4; ++i) {
+            const float4 r = refp[i];
+            ref2[2 * i] = f32x2{r.x, r.y} * (1.0f / CPG);
+            ref2[2 * i + 1] = f32x2{r.z, r.w} * (1.0f / CPG);
         }
     }
-    if constexpr (DEFER) {
-        if (bf.cursor != nullptr) write_claimed_items();
+    const unsigned at = (unsigned)d * (unsigned)HW + (unsigned)p;       // inside one batch item of a [B,*,D,H,W] tensor
+    const float hyp = hypo[(size_t)b * D * HW + at];
+    const float rden = div_fast(1.0f, wsum[(size_t)b * D * HW + at]);
+    float gd[G], godot = 0.0f;
+    {
+        const float* __restrict__ gvolb = gvol + (size_t)b * G * D * HW;
+        const float* __restrict__ volb = vol + (size_t)b * G * D * HW;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const unsigned ag = at + (unsigned)(g * D) * (unsigned)HW;
+            gd[g] = gvolb[ag] * rden;
+            godot = fmaf(gd[g], volb[ag], godot);
+        }
     }
+    f32x2 dref[C / 2];
+#pragma unroll
+    for (int i = 0; i < C / 2; ++i) dref[i] = f32x2{0.0f, 0.0f};
+
+    const LaneMasks lm = lane_masks(lane);
+    const int item = pack_item(own.x, own.y, d);
+    __shared__ BinAgg agg;
+    __shared__ int places[kAggViews][kBlock];
+    const bool filling = bf.cursor != nullptr;
+    if (filling) agg_reset(agg);
+    for (int s = 0; s < dm.S; ++s) {
+        const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C;
+        const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
+        const Landing l = land(q, rotate_pixel(q, fx, fy), hyp, dm.Hs, dm.Ws);
+        if (filling)                                                             // wave-uniform
+            places[s % kAggViews][threadIdx.x] = agg_claim<0>(agg, s % kAggViews, bf, bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view * kBinCats,
+                                                              l, live, lane, lm, item);
+        unsigned o[4];
+        float w4[4];
+        tap_addresses<C>(l, dm.Hs, dm.Ws, o, w4);
+        float cor[G];
+        f32x2 warped[C / 2];
+        gather_correlate<C, CPG, true>(srcb, o, w4, ref2, cor, warped);
+        float sg = cor[0];
+#pragma unroll
+        for (int g = 1; g < G; ++g) sg += cor[g];
+        const float a = div_temp(sg, dm);
+        const float m = group_max<D>(a);
+        const float e = exp_nonpos(a - m);
+        const float what = div_fast(e, group_sum<D>(e));
+        float dw = -godot;
+#pragma unroll
+        for (int g = 0; g < G; ++g) dw = fmaf(gd[g], cor[g], dw);
+        const float sdot = group_sum<D>(what * dw);
+        const float da = what * (dw - sdot) * dm.inv_tc;
+        const float w = div_sqrt_c(what, dm);
+        float coef[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) coef[g] = fmaf(gd[g], w, da) * (1.0f / CPG);
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) {
+            const f32x2 cf = {coef[(2 * i) / CPG], coef[(2 * i + 1) / CPG]};
+            dref[i] = __builtin_elementwise_fma(cf, warped[i], dref[i]);
+        }
+        if (live) {
+            float4* __restrict__ out = reinterpret_cast<float4*>(dcor_out + ((((size_t)b * dm.S + s) * HW + p) * D + d) * G);
+#pragma unroll
+            for (int g4 = 0; g4 < G / 4; ++g4) out[g4] = make_float4(coef[4 * g4], coef[4 * g4 + 1], coef[4 * g4 + 2], coef[4 * g4 + 3]);
+        }
+        if (filling && (s % kAggViews == kAggViews - 1 || s == dm.S - 1)) {      // the batch's slots: one claim per occupied entry
+            agg_flush_claims(agg, bf.cursor, bf.tiles_per_view * kBinCats, b, dm.S, s - s % kAggViews);
+            for (int v = 0; v <= s % kAggViews; ++v) agg_write_item<0>(agg, v, bf, places[v][threadIdx.x], lane, item);
+        }
+    }
+    // reference gradient: sum over the D hypothesis lanes of the pixel, lane d stores channels [d C/D', ...)
     float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C);
     float* __restrict__ gref_planes = gref + (size_t)b * C * HW + p;            // MVSTER_GRAD_PLANAR: [B,C,H,W]
 #pragma unroll
-    for (int c4 = 0; c4 < C4; ++c4) {
+    for (int c4 = 0; c4 < C / 4; ++c4) {
         float4 v;
-        v.x = group_sum<DL>(dref[4 * c4 + 0]);
-        v.y = group_sum<DL>(dref[4 * c4 + 1]);
-        v.z = group_sum<DL>(dref[4 * c4 + 2]);
-        v.w = group_sum<DL>(dref[4 * c4 + 3]);
-        if (live && dl == 0) {
+        v.x = group_sum<D>(dref[2 * c4].x);
+        v.y = group_sum<D>(dref[2 * c4].y);
+        v.z = group_sum<D>(dref[2 * c4 + 1].x);
+        v.w = group_sum<D>(dref[2 * c4 + 1].y);
+        if (live && d == c4 % D) {                                              // spread the stores over the pixel's lanes
             if (dm.grad_planar) {                                                // wave-uniform
                 gref_planes[(size_t)(4 * c4 + 0) * HW] = v.x;
                 gref_planes[(size_t)(4 * c4 + 1) * HW] = v.y;
@@ -514,8 +543,7 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
     const int p = live ? praw : HW - 1;
     const int y = p / dm.W, x = p - y * dm.W;
     const float fx = (float)x, fy = (float)y;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
-    const float inv_tc = 1.0f / (dm.temp * dm.sqrt_c);
+    const float inv_tc = dm.inv_tc;
     const int lane = threadIdx.x & 63;
     float (*strip)[Wn::kStrip] = stage[threadIdx.x >> 6];
     float* __restrict__ mine = strip[lane];
@@ -526,7 +554,7 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         hyp[d] = hypo[((size_t)b * D + d) * HW + p];
-        const float rden = 1.0f / wsum[((size_t)b * D + d) * HW + p];
+        const float rden = div_fast(1.0f, wsum[((size_t)b * D + d) * HW + p]);
         float acc = 0.0f;
 #pragma unroll
         for (int g = 0; g < GL; ++g) {
@@ -549,7 +577,7 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
         float warped[CL][D], cor[GL][D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            taps[d] = project_taps(q, ray, hyp[d], dm.Hs, dm.Ws, half_w, half_h);
+            taps[d] = project_taps(q, ray, hyp[d], dm.Hs, dm.Ws);
             const Taps& t = taps[d];
             const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
             const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
@@ -597,13 +625,13 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
         float e[D], sum = 0.0f;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            e[d] = expf(a[d] - m);
+            e[d] = exp_nonpos(a[d] - m);
             sum += e[d];
         }
         float what[D], dw[D], sdot = 0.0f;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            what[d] = e[d] / sum;
+            what[d] = div_fast(e[d], sum);
             float acc = 0.0f;
 #pragma unroll
             for (int g = 0; g < GL; ++g) acc = fmaf(gd[g][d], cor[g][d], acc);
@@ -616,7 +644,7 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const float da = what[d] * (dw[d] - sdot) * inv_tc;
-            const float w = what[d] / dm.sqrt_c;
+            const float w = div_sqrt_c(what[d], dm);
             float dwarp[CL];
 #pragma unroll
             for (int c4 = 0; c4 < CL4; ++c4) {
@@ -665,7 +693,7 @@ cost_volume_bwd_nhwc_split_kernel(const float* __restrict__ gvol, const float* _
 }
 
 // ------------------------------------------------------------------------------- coefficient kernel, C >= 32: channel-split lanes
-// The DEFER kernel above with a sample shared by HS = C / 16 adjacent lanes of 16 channels each (see
+// The coefficient kernel above with a sample shared by HS = C / 16 adjacent lanes of 16 channels each (see
 // cost_volume_fwd_split_kernel): 284 -> ~130 VGPRs at C = 64.  Only the sums over ALL correlation groups (softmax input,
 // dw, godot) cross the lanes of a sample; every lane stores the coefficients of its own groups and the reference gradient
 // of its own channels.  Lanes of a pixel: [d][h], h fastest.  Always deferred (coefficients out, no scatter here).
@@ -675,11 +703,13 @@ cost_volume_bwd_coef_split_kernel(const float* __restrict__ gvol, const float* _
                                   const float* __restrict__ wsum, const float* __restrict__ ref, SrcPtrs srcs,
                                   const float* __restrict__ pose, const float* __restrict__ hypo, float* __restrict__ gref,
                                   VolumeDims dm, float* __restrict__ dcor_out, BinFill bf) {
-    constexpr int CPG = C / G, CL = C / HS, CL4 = CL / 4, GL = G / HS;
+    constexpr int CPG = C / G, CL = C / HS, GL = G / HS;
     static_assert(CL == 16 && CL % CPG == 0 && GL >= 1, "16 channels = whole correlation groups per lane");
     constexpr int LPP = D * HS;
     static_assert(LPP <= kWave, "a pixel's lanes live in one wave");
     constexpr int PXB = kBlock / LPP;
+    constexpr int HSLOG = HS == 2 ? 1 : 2;
+    static_assert(HS == 2 || HS == 4, "C = 32 or 64");
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     if (tile >= dm.ntiles) return;
     const int b = blockIdx.y;
@@ -690,120 +720,95 @@ cost_volume_bwd_coef_split_kernel(const float* __restrict__ gvol, const float* _
     const bool live = praw < HW;
     const int p = live ? praw : HW - 1;
     const int y = p / dm.W, x = p - y * dm.W;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
-    const float inv_tc = 1.0f / (dm.temp * dm.sqrt_c);
 
-    const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C + h * CL);
-    float4 refv[CL4];
+    f32x2 ref2[CL / 2];
+    {
+        const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C + h * CL);
 #pragma unroll
-    for (int q4 = 0; q4 < CL4; ++q4) refv[q4] = refp[q4];
+        for (int i = 0; i < CL / 4; ++i) {
+            const float4 r = refp[i];
+            ref2[2 * i] = f32x2{r.x, r.y} * (1.0f / CPG);
+            ref2[2 * i + 1] = f32x2{r.z, r.w} * (1.0f / CPG);
+        }
+    }
     const float hyp = hypo[((size_t)b * D + d) * HW + p];
-    const float rden = 1.0f / wsum[((size_t)b * D + d) * HW + p];
+    const float rden = div_fast(1.0f, wsum[((size_t)b * D + d) * HW + p]);
     float gd[GL], godot = 0.0f;
 #pragma unroll
     for (int g = 0; g < GL; ++g) {
         const size_t at = (((size_t)b * G + h * GL + g) * D + d) * HW + p;
-        gd[g] = live ? gvol[at] * rden : 0.0f;
+        gd[g] = gvol[at] * rden;
         godot = fmaf(gd[g], vol[at], godot);
     }
     godot = strided_sum<HS, 1>(godot);
-    float dref[CL];
+    f32x2 dref[CL / 2];
 #pragma unroll
-    for (int c = 0; c < CL; ++c) dref[c] = 0.0f;
+    for (int i = 0; i < CL / 2; ++i) dref[i] = f32x2{0.0f, 0.0f};
 
-    // second pass of the counting sort, as in the DEFER kernel: claims are consumed one view later
-    int claim_leader[4] = {-1, -1, -1, -1}, claim_rank[4] = {0, 0, 0, 0}, claim_base[4] = {0, 0, 0, 0};
-    auto write_claimed_items = [&]() {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (__ballot(claim_leader[k] >= 0) == 0) continue;
-            const int base = __shfl(claim_base[k], max(claim_leader[k], 0), kWave);
-            if (claim_leader[k] >= 0) bf.items[base + claim_rank[k]] = p * D + d;
-        }
-    };
-
+    const LaneMasks lm = lane_masks(lane);
+    const int item = pack_item(x, y, d);
+    __shared__ BinAgg agg;
+    __shared__ int places[kAggViews][kBlock];
+    const bool filling = bf.cursor != nullptr;
+    if (filling) agg_reset(agg);
     for (int s = 0; s < dm.S; ++s) {
         const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C + h * CL;
         const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
-        const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws, half_w, half_h);
-        const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
-        const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
-        const float4* __restrict__ p10 = reinterpret_cast<const float4*>(srcb + (size_t)t.o10 * C);
-        const float4* __restrict__ p11 = reinterpret_cast<const float4*>(srcb + (size_t)t.o11 * C);
-        float warped[CL], cg[GL];
+        const Landing l = land(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws);
+        if (filling)                                                             // wave-uniform
+            places[s % kAggViews][threadIdx.x] = agg_claim<HSLOG>(agg, s % kAggViews, bf, bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view * kBinCats,
+                                                                  l, live, lane, lm, item);
+        unsigned o[4];
+        float w4[4];
+        tap_addresses<C>(l, dm.Hs, dm.Ws, o, w4);
+        float cor[GL];
+        f32x2 warped[CL / 2];
+        gather_correlate<CL, CPG, true>(srcb, o, w4, ref2, cor, warped);
+        float sg = cor[0], dwl = gd[0] * cor[0];
 #pragma unroll
-        for (int g = 0; g < GL; ++g) cg[g] = 0.0f;
-#pragma unroll
-        for (int c4 = 0; c4 < CL4; ++c4) {
-            const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
-            const float4 r = refv[c4];
-            warped[4 * c4 + 0] = fmaf(dq.x, t.w11, fmaf(cq.x, t.w10, fmaf(bq.x, t.w01, a.x * t.w00)));
-            warped[4 * c4 + 1] = fmaf(dq.y, t.w11, fmaf(cq.y, t.w10, fmaf(bq.y, t.w01, a.y * t.w00)));
-            warped[4 * c4 + 2] = fmaf(dq.z, t.w11, fmaf(cq.z, t.w10, fmaf(bq.z, t.w01, a.z * t.w00)));
-            warped[4 * c4 + 3] = fmaf(dq.w, t.w11, fmaf(cq.w, t.w10, fmaf(bq.w, t.w01, a.w * t.w00)));
-            cg[(4 * c4 + 0) / CPG] = fmaf(warped[4 * c4 + 0], r.x, cg[(4 * c4 + 0) / CPG]);
-            cg[(4 * c4 + 1) / CPG] = fmaf(warped[4 * c4 + 1], r.y, cg[(4 * c4 + 1) / CPG]);
-            cg[(4 * c4 + 2) / CPG] = fmaf(warped[4 * c4 + 2], r.z, cg[(4 * c4 + 2) / CPG]);
-            cg[(4 * c4 + 3) / CPG] = fmaf(warped[4 * c4 + 3], r.w, cg[(4 * c4 + 3) / CPG]);
-        }
-        float cor[GL], sg = 0.0f, dwl = 0.0f;
-#pragma unroll
-        for (int g = 0; g < GL; ++g) {
-            cor[g] = cg[g] * (1.0f / CPG);
-            sg = g == 0 ? cor[0] : sg + cor[g];
+        for (int g = 1; g < GL; ++g) {
+            sg += cor[g];
             dwl = fmaf(gd[g], cor[g], dwl);
         }
         sg = strided_sum<HS, 1>(sg);
         const float dw = strided_sum<HS, 1>(dwl) - godot;
         const float a = div_temp(sg, dm);
         const float m = strided_max<D, HS>(a);
-        const float e = expf(a - m);
-        const float what = e / strided_sum<D, HS>(e);
+        const float e = exp_nonpos(a - m);
+        const float what = div_fast(e, strided_sum<D, HS>(e));
         const float sdot = strided_sum<D, HS>(what * dw);
-        const float da = what * (dw - sdot) * inv_tc;
-        const float w = what / dm.sqrt_c;
+        const float da = what * (dw - sdot) * dm.inv_tc;
+        const float w = div_sqrt_c(what, dm);
         float coef[GL];
 #pragma unroll
         for (int g = 0; g < GL; ++g) coef[g] = fmaf(gd[g], w, da) * (1.0f / CPG);
 #pragma unroll
-        for (int c = 0; c < CL; ++c) dref[c] = fmaf(coef[c / CPG], warped[c], dref[c]);
+        for (int i = 0; i < CL / 2; ++i) {
+            const f32x2 cf = {coef[(2 * i) / CPG], coef[(2 * i + 1) / CPG]};
+            dref[i] = __builtin_elementwise_fma(cf, warped[i], dref[i]);
+        }
         if (live) {
             float* __restrict__ out = dcor_out + ((((size_t)b * dm.S + s) * HW + p) * D + d) * G + h * GL;
             if constexpr (GL == 4) *reinterpret_cast<float4*>(out) = make_float4(coef[0], coef[1], coef[2], coef[3]);
             else if constexpr (GL == 2) *reinterpret_cast<float2*>(out) = make_float2(coef[0], coef[1]);
             else out[0] = coef[0];
         }
-        if (bf.cursor != nullptr) {                                              // wave-uniform
-            write_claimed_items();
-            int id[4];
-            bool emit[4];
-            footprint_tiles(t, bf.bg, id, emit);
-            int* __restrict__ cur = bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view;
-            const bool straddles = __ballot(live && h == 0 && (emit[1] | emit[2] | emit[3])) != 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k > 0 && !straddles) {
-                    claim_leader[k] = -1;
-                    continue;
-                }
-                int count;
-                wave_group(id[k], live && h == 0 && emit[k], lane, claim_leader[k], claim_rank[k], count);
-                claim_base[k] = lane == claim_leader[k] ? atomicAdd(cur + id[k], count) : 0;
-            }
+        if (filling && (s % kAggViews == kAggViews - 1 || s == dm.S - 1)) {
+            agg_flush_claims(agg, bf.cursor, bf.tiles_per_view * kBinCats, b, dm.S, s - s % kAggViews);
+            for (int v = 0; v <= s % kAggViews; ++v) agg_write_item<HSLOG>(agg, v, bf, places[v][threadIdx.x], lane, item);
         }
     }
-    if (bf.cursor != nullptr) write_claimed_items();
     // reference gradient: sum over the D hypothesis lanes of this channel part
     float4* __restrict__ grefp = reinterpret_cast<float4*>(gref + ((size_t)b * HW + p) * C + h * CL);
     float* __restrict__ gref_planes = gref + ((size_t)b * C + h * CL) * HW + p;
 #pragma unroll
-    for (int c4 = 0; c4 < CL4; ++c4) {
+    for (int c4 = 0; c4 < CL / 4; ++c4) {
         float4 v;
-        v.x = strided_sum<D, HS>(dref[4 * c4 + 0]);
-        v.y = strided_sum<D, HS>(dref[4 * c4 + 1]);
-        v.z = strided_sum<D, HS>(dref[4 * c4 + 2]);
-        v.w = strided_sum<D, HS>(dref[4 * c4 + 3]);
-        if (live && d == 0) {
+        v.x = strided_sum<D, HS>(dref[2 * c4].x);
+        v.y = strided_sum<D, HS>(dref[2 * c4].y);
+        v.z = strided_sum<D, HS>(dref[2 * c4 + 1].x);
+        v.w = strided_sum<D, HS>(dref[2 * c4 + 1].y);
+        if (live && d == c4 % D) {
             if (dm.grad_planar) {
                 gref_planes[(size_t)(4 * c4 + 0) * HW] = v.x;
                 gref_planes[(size_t)(4 * c4 + 1) * HW] = v.y;
@@ -816,7 +821,7 @@ cost_volume_bwd_coef_split_kernel(const float* __restrict__ gvol, const float* _
     }
 }
 
-// deferred routes (see DEFER above): coefficients first, then either the tiled LDS-merged atomic scatter of
+// deferred routes: coefficients first, then either the tiled LDS-merged atomic scatter of
 // cost_volume_scatter.hip or the binned, atomics-free scatter of cost_volume_binned.hip
 template <int CPG, int G, int D>
 static int launch_bwd_deferred(const float* gvol, const float* vol, const float* wsum, const float* ref, const SrcPtrs& srcs,
@@ -837,6 +842,7 @@ static int launch_bwd_deferred(const float* gvol, const float* vol, const float*
         bf.items = words + lay.items;
         bf.bg = bin_grid_for(CPG * G, dm.Hs, dm.Ws);
         bf.tiles_per_view = bf.bg.tiles_x * bf.bg.tiles_y;
+        bf.max_items = (int)lay.max_items;
     }
     if constexpr (CPG * G >= 32) {
         constexpr int HS = CPG * G / 16;
@@ -845,8 +851,8 @@ static int launch_bwd_deferred(const float* gvol, const float* vol, const float*
         hipLaunchKernelGGL((cost_volume_bwd_coef_split_kernel<CPG * G, G, D, HS>), grid2, dim3(kBlock), 0, st, gvol, vol, wsum,
                            ref, srcs, pose, hypo, gref, dm, dcor, bf);
     } else {
-        hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, 1, true>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
-                           ref, srcs, pose, hypo, gref, gsrcs, dm, dcor, bf);
+        hipLaunchKernelGGL((cost_volume_bwd_coef_kernel<CPG * G, G, D>), grid, dim3(kBlock), 0, st, gvol, vol, wsum,
+                           ref, srcs, pose, hypo, gref, dm, dcor, bf);
     }
     if (int rc = launch_status()) return rc;
     if (route == MVSTER_BWD_ROUTE_BINNED)
@@ -877,7 +883,7 @@ static int launch_bwd(const float* gvol, const float* vol, const float* wsum, co
         grid = dim3(((dm.ntiles + 7) / 8) * 8, B);
         if constexpr (DPL == 1)
             hipLaunchKernelGGL((cost_volume_bwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, gvol, vol,
-                               wsum, ref, srcs, pose, hypo, gref, gsrcs, dm, static_cast<float*>(nullptr), BinFill{});
+                               wsum, ref, srcs, pose, hypo, gref, gsrcs, dm);
         else
             return MVSTER_ERR_UNSUPPORTED;
     } else
@@ -934,7 +940,7 @@ extern "C" int mvster_cost_volume_bwd_route_name(int route, int C, int G, int D,
             break;
         }
         case MVSTER_BWD_ROUTE_DENSE:
-            n = snprintf(tmp, sizeof tmp, "cost_volume_bwd_nhwc_kernel<%d, %d, %d, 1, false>", C, G, D);
+            n = snprintf(tmp, sizeof tmp, "cost_volume_bwd_nhwc_kernel<%d, %d, %d, 1>", C, G, D);
             break;
         case MVSTER_BWD_ROUTE_SPLIT_WINDOW:
             n = snprintf(tmp, sizeof tmp, "cost_volume_bwd_nhwc_split_kernel<%d, %d, 4, %d>", C, G, C == 16 ? 4 : 2);
@@ -948,7 +954,7 @@ extern "C" int mvster_cost_volume_bwd_route_name(int route, int C, int G, int D,
             if (C == 8) snprintf(owner, sizeof owner, "tile_owner_c8_kernel<%d, %d>", G, D);
             else snprintf(owner, sizeof owner, "tile_owner_kernel<%d, %d, %d>", C, G, D);
             if (C >= 32) snprintf(coef, sizeof coef, "cost_volume_bwd_coef_split_kernel<%d, %d, %d, %d>", C, G, D, C / 16);
-            else snprintf(coef, sizeof coef, "cost_volume_bwd_nhwc_kernel<%d, %d, %d, 1, true>", C, G, D);
+            else snprintf(coef, sizeof coef, "cost_volume_bwd_coef_kernel<%d, %d, %d>", C, G, D);
             n = snprintf(tmp, sizeof tmp, "%s;%s", owner, coef);
             break;
         }

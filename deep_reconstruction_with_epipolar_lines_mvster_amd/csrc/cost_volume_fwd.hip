@@ -39,7 +39,6 @@ cost_volume_fwd_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float*
     const int p = live ? praw : HW - 1;
     const int y = p / dm.W, x = p - y * dm.W;
     const float fx = (float)x, fy = (float)y;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
 
     const float* __restrict__ refp = ref + (size_t)b * C * HW + p;
     float refv[kRefInRegs ? C : 1];
@@ -66,17 +65,23 @@ cost_volume_fwd_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float*
         float cor[G][DPL];
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
-            const Taps t = project_taps(q, ray, hyp[j], dm.Hs, dm.Ws, half_w, half_h);
+            const Taps t = project_taps(q, ray, hyp[j], dm.Hs, dm.Ws);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                float acc = 0.0f;
+                // same association as the channels-last kernels (gather_correlate): even and odd channels of a group
+                // accumulate separately, the reference feature carries the 1 / CPG of the group mean (:1069)
+                float ax = 0.0f, ay = 0.0f;
 #pragma unroll
                 for (int k = 0; k < CPG; ++k) {
                     const int c = g * CPG + k;
-                    const float r = kRefInRegs ? refv[kRefInRegs ? c : 0] : refp[(size_t)c * HW];
-                    acc = fmaf(sample(srcb + (size_t)c * HWs, t), r, acc);
+                    const float r = (kRefInRegs ? refv[kRefInRegs ? c : 0] : refp[(size_t)c * HW]) * (1.0f / CPG);
+                    const float v = sample(srcb + (size_t)c * HWs, t);
+                    if (k == 0) ax = v * r;
+                    else if (k == 1) ay = v * r;
+                    else if (k % 2 == 0) ax = fmaf(v, r, ax);
+                    else ay = fmaf(v, r, ay);
                 }
-                cor[g][j] = acc * (1.0f / CPG);           // mean over the group's channels (:1069)
+                cor[g][j] = CPG == 1 ? ax : ax + ay;
             }
         }
         // view weight: softmax over ALL D hypotheses of sum_g cor / temp, then / sqrt(C)  (:1083)
@@ -93,13 +98,13 @@ cost_volume_fwd_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float*
         float e[DPL], sum = 0.0f;
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
-            e[j] = expf(a[j] - m);
+            e[j] = exp_nonpos(a[j] - m);
             sum += e[j];
         }
         sum = group_sum<DL>(sum);
 #pragma unroll
         for (int j = 0; j < DPL; ++j) {
-            const float w = (e[j] / sum) / dm.sqrt_c;
+            const float w = div_sqrt_c(div_fast(e[j], sum), dm);
             den[j] += w;                                   // (:1084)
 #pragma unroll
             for (int g = 0; g < G; ++g) num[g][j] += w * cor[g][j];   // (:1085)
@@ -110,7 +115,7 @@ cost_volume_fwd_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float*
     for (int j = 0; j < DPL; ++j) {
         const int d = dl * DPL + j;
 #pragma unroll
-        for (int g = 0; g < G; ++g) vol[(((size_t)b * G + g) * D + d) * HW + p] = num[g][j] / den[j];   // (:1100)
+        for (int g = 0; g < G; ++g) vol[(((size_t)b * G + g) * D + d) * HW + p] = div_fast(num[g][j], den[j]);   // (:1100)
         if (wsum != nullptr) wsum[((size_t)b * D + d) * HW + p] = den[j];
     }
 }
@@ -122,111 +127,89 @@ cost_volume_fwd_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float*
 // tap pair however incoherent neighbouring pixels' depths are, instead of one sector per (tap, channel)
 // as with NCHW planes -- this is the layout the training/inference path uses (hotpath.py converts once per
 // stage, or takes channels_last tensors as they are).
+//
+// Round 3: written for VALU instruction count (the round-2 kernel issued ~415 wave-instructions per (sample, view), 95 %
+// of its run time): lean projection (mvster_device.h land()), taps addressed by 32-bit byte offsets from the view's
+// uniform base pointer, channel pairs interpolated and correlated with packed fp32 instructions, the 1 / CPG of the group
+// mean folded into the reference feature (a power of two: exact), DPP reductions over the D lanes of a pixel, reciprocal
+// + residual instead of IEEE divisions.
+
 template <int C, int G, int D, int DPL>
 __global__ void __launch_bounds__(kBlock)
 cost_volume_fwd_nhwc_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float* __restrict__ pose,
                             const float* __restrict__ hypo, float* __restrict__ vol, float* __restrict__ wsum,
                             VolumeDims dm, BinCount bc) {
+    static_assert(DPL == 1 && C <= 16, "one lane per (pixel, hypothesis); C >= 32 runs the channel-split kernel");
     constexpr int CPG = C / G;
-    constexpr int C4 = C / 4;
-    constexpr int DL = D / DPL;
-    constexpr int PXB = kBlock / DL;
-    constexpr bool kRefInRegs = (C <= 16);
+    constexpr int PXB = kBlock / D;
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     if (tile >= dm.ntiles) return;
     const int b = blockIdx.y;
     const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
-    const int dl = threadIdx.x % DL, pl = threadIdx.x / DL;
+    const int lane = threadIdx.x & 63;
+    const int d = threadIdx.x % D, pl = threadIdx.x / D;
     const OwnedPixel own = owned_pixel<PXB>(tile, pl, dm.H, dm.W);
     const bool live = own.live;
-    const int p = own.p, y = own.y, x = own.x;
-    const float fx = (float)x, fy = (float)y;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
+    const int p = own.p;
+    const float fx = (float)own.x, fy = (float)own.y;
 
-    const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C);
-    float4 refv[kRefInRegs ? C4 : 1];
-    if constexpr (kRefInRegs) {
+    f32x2 ref2[C / 2];
+    {
+        const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C);
 #pragma unroll
-        for (int q = 0; q < C4; ++q) refv[q] = refp[q];
+        for (int i = 0; i < C / 4; ++i) {
+            const float4 r = refp[i];
+            ref2[2 * i] = f32x2{r.x, r.y} * (1.0f / CPG);          // mean over the group's channels (:1069), exact scaling
+            ref2[2 * i + 1] = f32x2{r.z, r.w} * (1.0f / CPG);
+        }
     }
-    float hyp[DPL];
+    const float hyp = hypo[((size_t)b * D + d) * HW + p];
+    float den = 1e-8f, num[G];                                     // cor_weight_sum starts at 1e-8 (:1037)
 #pragma unroll
-    for (int j = 0; j < DPL; ++j) hyp[j] = hypo[((size_t)b * D + dl * DPL + j) * HW + p];
-
-    float den[DPL], num[G][DPL];
-#pragma unroll
-    for (int j = 0; j < DPL; ++j) {
-        den[j] = 1e-8f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) num[g][j] = 0.0f;
-    }
+    for (int g = 0; g < G; ++g) num[g] = 0.0f;
+    const LaneMasks lm = lane_masks(lane);
+    __shared__ BinAgg agg;
+    const bool counting = bc.counters != nullptr;                  // training: first pass of the backward's counting sort
+    if (counting) agg_reset(agg);
 
     for (int s = 0; s < dm.S; ++s) {
         const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C;
         const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
-        const Ray ray = rotate_pixel(q, fx, fy);
-        float cor[G][DPL];
-#pragma unroll
-        for (int j = 0; j < DPL; ++j) {
-            const Taps t = project_taps(q, ray, hyp[j], dm.Hs, dm.Ws, half_w, half_h);
-            if (bc.counters != nullptr)          // training: first pass of the backward's counting sort (wave-uniform branch)
-                count_sample(bc, bc.counters + ((size_t)b * dm.S + s) * bc.tiles_per_view, t, live, threadIdx.x & 63);
-            const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
-            const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
-            const float4* __restrict__ p10 = reinterpret_cast<const float4*>(srcb + (size_t)t.o10 * C);
-            const float4* __restrict__ p11 = reinterpret_cast<const float4*>(srcb + (size_t)t.o11 * C);
-            float cg[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) cg[g] = 0.0f;
-#pragma unroll
-            for (int c4 = 0; c4 < C4; ++c4) {
-                const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
-                const float4 r = kRefInRegs ? refv[kRefInRegs ? c4 : 0] : refp[c4];
-                const float w0 = fmaf(dq.x, t.w11, fmaf(cq.x, t.w10, fmaf(bq.x, t.w01, a.x * t.w00)));
-                const float w1 = fmaf(dq.y, t.w11, fmaf(cq.y, t.w10, fmaf(bq.y, t.w01, a.y * t.w00)));
-                const float w2 = fmaf(dq.z, t.w11, fmaf(cq.z, t.w10, fmaf(bq.z, t.w01, a.z * t.w00)));
-                const float w3 = fmaf(dq.w, t.w11, fmaf(cq.w, t.w10, fmaf(bq.w, t.w01, a.w * t.w00)));
-                cg[(4 * c4 + 0) / CPG] = fmaf(w0, r.x, cg[(4 * c4 + 0) / CPG]);
-                cg[(4 * c4 + 1) / CPG] = fmaf(w1, r.y, cg[(4 * c4 + 1) / CPG]);
-                cg[(4 * c4 + 2) / CPG] = fmaf(w2, r.z, cg[(4 * c4 + 2) / CPG]);
-                cg[(4 * c4 + 3) / CPG] = fmaf(w3, r.w, cg[(4 * c4 + 3) / CPG]);
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) cor[g][j] = cg[g] * (1.0f / CPG);
+        const Landing l = land(q, rotate_pixel(q, fx, fy), hyp, dm.Hs, dm.Ws);
+        if (counting) {                                            // wave-uniform
+            const int v = s % kAggViews;
+            agg_count<0>(agg, v, bc, bc.counters + ((size_t)b * dm.S + s) * bc.tiles_per_view * kBinCats, l, live, lane, lm);
+            if (v == kAggViews - 1 || s == dm.S - 1) agg_flush_counts(agg, bc.counters, bc.tiles_per_view * kBinCats, b, dm.S, s - v);
         }
-        float a[DPL], m = -INFINITY;
+        unsigned o[4];
+        float w[4];
+        tap_addresses<C>(l, dm.Hs, dm.Ws, o, w);
+        float cor[G];
+        f32x2 unused[1];
+        gather_correlate<C, CPG, false>(srcb, o, w, ref2, cor, unused);
+        // view weight: softmax over ALL D hypotheses of sum_g cor / temp, then / sqrt(C)  (:1083)
+        float sg = cor[0];
 #pragma unroll
-        for (int j = 0; j < DPL; ++j) {
-            float sg = cor[0][j];
+        for (int g = 1; g < G; ++g) sg += cor[g];
+        const float a = div_temp(sg, dm);
+        const float m = group_max<D>(a);
+        const float e = exp_nonpos(a - m);
+        const float sum = group_sum<D>(e);
+        const float wv = div_sqrt_c(div_fast(e, sum), dm);
+        den += wv;                                                 // (:1084)
 #pragma unroll
-            for (int g = 1; g < G; ++g) sg += cor[g][j];
-            a[j] = div_temp(sg, dm);
-            m = fmaxf(m, a[j]);
-        }
-        m = group_max<DL>(m);
-        float e[DPL], sum = 0.0f;
-#pragma unroll
-        for (int j = 0; j < DPL; ++j) {
-            e[j] = expf(a[j] - m);
-            sum += e[j];
-        }
-        sum = group_sum<DL>(sum);
-#pragma unroll
-        for (int j = 0; j < DPL; ++j) {
-            const float w = (e[j] / sum) / dm.sqrt_c;
-            den[j] += w;
-#pragma unroll
-            for (int g = 0; g < G; ++g) num[g][j] += w * cor[g][j];
-        }
+        for (int g = 0; g < G; ++g) num[g] += wv * cor[g];         // (:1085)
     }
     if (!live) return;
+    const float rden = rcp_approx(den);
+    float* __restrict__ volb = vol + (size_t)b * G * D * HW;
+    const unsigned at = (unsigned)d * (unsigned)HW + (unsigned)p;
 #pragma unroll
-    for (int j = 0; j < DPL; ++j) {
-        const int d = dl * DPL + j;
-#pragma unroll
-        for (int g = 0; g < G; ++g) vol[(((size_t)b * G + g) * D + d) * HW + p] = num[g][j] / den[j];
-        if (wsum != nullptr) wsum[((size_t)b * D + d) * HW + p] = den[j];
+    for (int g = 0; g < G; ++g) {                                  // num / den (:1100)
+        const float qn = num[g] * rden;
+        volb[at + (unsigned)(g * D) * (unsigned)HW] = fmaf(fmaf(-qn, den, num[g]), rden, qn);
     }
+    if (wsum != nullptr) wsum[(size_t)b * D * HW + at] = den;
 }
 
 // ------------------------------------------------------------------------------- forward, C >= 32: channel-split lanes
@@ -240,76 +223,74 @@ __global__ void __launch_bounds__(kBlock)
 cost_volume_fwd_split_kernel(const float* __restrict__ ref, SrcPtrs srcs, const float* __restrict__ pose,
                              const float* __restrict__ hypo, float* __restrict__ vol, float* __restrict__ wsum,
                              VolumeDims dm, BinCount bc) {
-    constexpr int CPG = C / G, CL = C / HS, CL4 = CL / 4, GL = G / HS;
+    constexpr int CPG = C / G, CL = C / HS, GL = G / HS;
     static_assert(CL == 16 && CL % CPG == 0 && GL >= 1, "16 channels = whole correlation groups per lane");
     constexpr int LPP = D * HS;                    // lanes per pixel
     static_assert(LPP <= kWave, "a pixel's lanes live in one wave");
     constexpr int PXB = kBlock / LPP;
+    constexpr int HSLOG = HS == 2 ? 1 : 2;
+    static_assert(HS == 2 || HS == 4, "C = 32 or 64");
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     if (tile >= dm.ntiles) return;
     const int b = blockIdx.y;
     const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
+    const int lane = threadIdx.x & 63;
     const int h = threadIdx.x % HS, d = (threadIdx.x / HS) % D, pl = threadIdx.x / LPP;
     const int praw = tile * PXB + pl;
     const bool live = praw < HW;
     const int p = live ? praw : HW - 1;
     const int y = p / dm.W, x = p - y * dm.W;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
 
-    const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C + h * CL);
-    float4 refv[CL4];
+    f32x2 ref2[CL / 2];
+    {
+        const float4* __restrict__ refp = reinterpret_cast<const float4*>(ref + ((size_t)b * HW + p) * C + h * CL);
 #pragma unroll
-    for (int q4 = 0; q4 < CL4; ++q4) refv[q4] = refp[q4];
+        for (int i = 0; i < CL / 4; ++i) {
+            const float4 r = refp[i];
+            ref2[2 * i] = f32x2{r.x, r.y} * (1.0f / CPG);
+            ref2[2 * i + 1] = f32x2{r.z, r.w} * (1.0f / CPG);
+        }
+    }
     const float hyp = hypo[((size_t)b * D + d) * HW + p];
     float den = 1e-8f, num[GL];
 #pragma unroll
     for (int g = 0; g < GL; ++g) num[g] = 0.0f;
+    const LaneMasks lm = lane_masks(lane);
+    __shared__ BinAgg agg;
+    const bool counting = bc.counters != nullptr;
+    if (counting) agg_reset(agg);
 
     for (int s = 0; s < dm.S; ++s) {
         const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C + h * CL;
         const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
-        const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws, half_w, half_h);
-        if (bc.counters != nullptr)
-            count_sample(bc, bc.counters + ((size_t)b * dm.S + s) * bc.tiles_per_view, t, live && h == 0, threadIdx.x & 63);
-        const float4* __restrict__ p00 = reinterpret_cast<const float4*>(srcb + (size_t)t.o00 * C);
-        const float4* __restrict__ p01 = reinterpret_cast<const float4*>(srcb + (size_t)t.o01 * C);
-        const float4* __restrict__ p10 = reinterpret_cast<const float4*>(srcb + (size_t)t.o10 * C);
-        const float4* __restrict__ p11 = reinterpret_cast<const float4*>(srcb + (size_t)t.o11 * C);
-        float cg[GL];
-#pragma unroll
-        for (int g = 0; g < GL; ++g) cg[g] = 0.0f;
-#pragma unroll
-        for (int c4 = 0; c4 < CL4; ++c4) {
-            const float4 a = p00[c4], bq = p01[c4], cq = p10[c4], dq = p11[c4];
-            const float4 r = refv[c4];
-            const float w0 = fmaf(dq.x, t.w11, fmaf(cq.x, t.w10, fmaf(bq.x, t.w01, a.x * t.w00)));
-            const float w1 = fmaf(dq.y, t.w11, fmaf(cq.y, t.w10, fmaf(bq.y, t.w01, a.y * t.w00)));
-            const float w2 = fmaf(dq.z, t.w11, fmaf(cq.z, t.w10, fmaf(bq.z, t.w01, a.z * t.w00)));
-            const float w3 = fmaf(dq.w, t.w11, fmaf(cq.w, t.w10, fmaf(bq.w, t.w01, a.w * t.w00)));
-            cg[(4 * c4 + 0) / CPG] = fmaf(w0, r.x, cg[(4 * c4 + 0) / CPG]);
-            cg[(4 * c4 + 1) / CPG] = fmaf(w1, r.y, cg[(4 * c4 + 1) / CPG]);
-            cg[(4 * c4 + 2) / CPG] = fmaf(w2, r.z, cg[(4 * c4 + 2) / CPG]);
-            cg[(4 * c4 + 3) / CPG] = fmaf(w3, r.w, cg[(4 * c4 + 3) / CPG]);
+        const Landing l = land(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws);
+        if (counting) {                                            // wave-uniform
+            const int v = s % kAggViews;
+            agg_count<HSLOG>(agg, v, bc, bc.counters + ((size_t)b * dm.S + s) * bc.tiles_per_view * kBinCats, l, live, lane, lm);
+            if (v == kAggViews - 1 || s == dm.S - 1) agg_flush_counts(agg, bc.counters, bc.tiles_per_view * kBinCats, b, dm.S, s - v);
         }
-        float cor[GL], sg = 0.0f;
+        unsigned o[4];
+        float w[4];
+        tap_addresses<C>(l, dm.Hs, dm.Ws, o, w);
+        float cor[GL];
+        f32x2 unused[1];
+        gather_correlate<CL, CPG, false>(srcb, o, w, ref2, cor, unused);
+        float sg = cor[0];
 #pragma unroll
-        for (int g = 0; g < GL; ++g) {
-            cor[g] = cg[g] * (1.0f / CPG);
-            sg = g == 0 ? cor[0] : sg + cor[g];
-        }
+        for (int g = 1; g < GL; ++g) sg += cor[g];
         sg = strided_sum<HS, 1>(sg);                                   // all G groups: every lane of the sample
         const float a = div_temp(sg, dm);
         const float m = strided_max<D, HS>(a);
-        const float e = expf(a - m);
+        const float e = exp_nonpos(a - m);
         const float sum = strided_sum<D, HS>(e);
-        const float w = (e / sum) / dm.sqrt_c;
-        den += w;
+        const float wv = div_sqrt_c(div_fast(e, sum), dm);
+        den += wv;
 #pragma unroll
-        for (int g = 0; g < GL; ++g) num[g] += w * cor[g];
+        for (int g = 0; g < GL; ++g) num[g] += wv * cor[g];
     }
     if (!live) return;
 #pragma unroll
-    for (int g = 0; g < GL; ++g) vol[(((size_t)b * G + h * GL + g) * D + d) * HW + p] = num[g] / den;
+    for (int g = 0; g < GL; ++g) vol[(((size_t)b * G + h * GL + g) * D + d) * HW + p] = div_fast(num[g], den);
     if (wsum != nullptr && h == 0) wsum[((size_t)b * D + d) * HW + p] = den;
 }
 
@@ -329,10 +310,13 @@ static int launch_fwd(const float* ref, const SrcPtrs& srcs, const float* pose, 
             return launch_status();
         }
     }
-    if (layout == MVSTER_LAYOUT_NHWC)
-        hipLaunchKernelGGL((cost_volume_fwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, ref, srcs,
-                           pose, hypo, vol, wsum, dm, bc);
-    else
+    if (layout == MVSTER_LAYOUT_NHWC) {
+        if constexpr (CPG * G <= 16)
+            hipLaunchKernelGGL((cost_volume_fwd_nhwc_kernel<CPG * G, G, D, DPL>), grid, dim3(kBlock), 0, st, ref, srcs,
+                               pose, hypo, vol, wsum, dm, bc);
+        else
+            return MVSTER_ERR_UNSUPPORTED;          // not reached: C >= 32 returned from the channel-split kernel above
+    } else
         hipLaunchKernelGGL((cost_volume_fwd_kernel<CPG, G, D, DPL>), grid, dim3(kBlock), 0, st, ref, srcs, pose, hypo,
                            vol, wsum, dm);
     return launch_status();

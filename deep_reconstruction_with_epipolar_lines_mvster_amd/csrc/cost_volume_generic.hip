@@ -64,7 +64,6 @@ cost_volume_generic_fwd_kernel(const float* __restrict__ ref, SrcPtrs srcs, cons
     const bool live = praw < HW, has_d = d < g.D, on = live && has_d;
     const int p = live ? praw : HW - 1, dd = has_d ? d : g.D - 1;
     const int y = p / dm.W, x = p - y * dm.W;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
     const float* __restrict__ refp = ref + (size_t)b * g.C * HW + p;
     const float hyp = hypo[((size_t)b * g.D + dd) * HW + p];
     float* __restrict__ volp = vol + ((size_t)b * g.Cc * g.D + dd) * HW + p;          // + cc * D * HW
@@ -72,7 +71,7 @@ cost_volume_generic_fwd_kernel(const float* __restrict__ ref, SrcPtrs srcs, cons
     for (int s = 0; s < dm.S; ++s) {
         const float* __restrict__ srcb = srcs.p[s] + (size_t)b * g.C * HWs;
         const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
-        const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws, half_w, half_h);
+        const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws);
         float a = 0.0f;
         for (int cc = 0; cc < g.Cc; ++cc) {
             const float cor = correlate(g, cc, refp, srcb, t, HW, HWs);
@@ -116,7 +115,6 @@ cost_volume_generic_bwd_kernel(const float* __restrict__ gvol, const float* __re
     const bool live = praw < HW, has_d = d < g.D, on = live && has_d;
     const int p = live ? praw : HW - 1, dd = has_d ? d : g.D - 1;
     const int y = p / dm.W, x = p - y * dm.W;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
     const float* __restrict__ refp = ref + (size_t)b * g.C * HW + p;
     const float hyp = hypo[((size_t)b * g.D + dd) * HW + p];
     const size_t vbase = ((size_t)b * g.Cc * g.D + dd) * HW + p;                        // + cc * D * HW
@@ -126,7 +124,7 @@ cost_volume_generic_bwd_kernel(const float* __restrict__ gvol, const float* __re
         const float* __restrict__ srcb = srcs.p[s] + (size_t)b * g.C * HWs;
         float* __restrict__ gsrcb = gsrcs.p[s] + (size_t)b * g.C * HWs;
         const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
-        const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws, half_w, half_h);
+        const Taps t = project_taps(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws);
         float a = 0.0f, dw = 0.0f;
         for (int cc = 0; cc < g.Cc; ++cc) {
             const float cor = correlate(g, cc, refp, srcb, t, HW, HWs);

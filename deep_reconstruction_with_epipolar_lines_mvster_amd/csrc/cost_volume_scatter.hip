@@ -88,7 +88,6 @@ tile_scatter_kernel(ScatterArgs a) {
     const int HW = dm.H * dm.W, HWs = dm.Hs * dm.Ws;
     const int C = a.C, G = a.G, cpg = C / G;
     const int c = chunk * kChunk + cl;
-    const float half_w = (float)((dm.Ws - 1) / 2.0), half_h = (float)((dm.Hs - 1) / 2.0);
     const Pose q = load_pose(a.pose + ((size_t)b * dm.S + s) * 12);
     float* __restrict__ gsrc = a.gsrcs.p[s] + (size_t)b * HWs * C + c;      // + pixel * C
     const float* __restrict__ dcor = a.dcor + ((size_t)b * dm.S + s) * HW * D * G + c / cpg;
@@ -115,8 +114,7 @@ tile_scatter_kernel(ScatterArgs a) {
         const bool live1 = live_x1 & (yr1 < dm.H);
         const int y1 = min(yr1, dm.H - 1);
         const int p1 = y1 * dm.W + x1;
-        const Taps t = project_taps(q, rotate_pixel(q, (float)x1, (float)y1), hypo[(size_t)d1 * HW + p1], dm.Hs, dm.Ws,
-                                    half_w, half_h);
+        const Taps t = project_taps(q, rotate_pixel(q, (float)x1, (float)y1), hypo[(size_t)d1 * HW + p1], dm.Hs, dm.Ws);
         TapRecord rec;
         const int e = t.ix + kRowStep * t.iy;                        // ix, iy >= -2
         rec.entry = (e + 128 * NB) % NB;

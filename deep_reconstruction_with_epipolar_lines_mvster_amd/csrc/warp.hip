@@ -21,12 +21,11 @@ warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ pose, c
     const int y = p / Wr, x = p - y * Wr;
     const Pose q = load_pose(pose + (size_t)b * 12);
     const Ray ray = rotate_pixel(q, (float)x, (float)y);
-    const float half_w = (float)((Ws - 1) / 2.0), half_h = (float)((Hs - 1) / 2.0);
     const float* __restrict__ srcb = src + (size_t)b * C * HWs;
     const float* __restrict__ depb = depth + (size_t)b * D * HW + p;
     float* __restrict__ outb = out + (size_t)b * C * D * HW + p;
     for (int d = 0; d < D; ++d) {
-        const Taps t = project_taps(q, ray, depb[(size_t)d * HW], Hs, Ws, half_w, half_h);
+        const Taps t = project_taps(q, ray, depb[(size_t)d * HW], Hs, Ws);
         for (int c = 0; c < C; ++c) outb[((size_t)c * D + d) * HW] = sample(srcb + (size_t)c * HWs, t);
     }
 }
@@ -41,12 +40,11 @@ warp_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ pose, 
     const int y = p / Wr, x = p - y * Wr;
     const Pose q = load_pose(pose + (size_t)b * 12);
     const Ray ray = rotate_pixel(q, (float)x, (float)y);
-    const float half_w = (float)((Ws - 1) / 2.0), half_h = (float)((Hs - 1) / 2.0);
     float* __restrict__ gsrcb = gsrc + (size_t)b * C * HWs;
     const float* __restrict__ depb = depth + (size_t)b * D * HW + p;
     const float* __restrict__ goutb = gout + (size_t)b * C * D * HW + p;
     for (int d = 0; d < D; ++d) {
-        const Taps t = project_taps(q, ray, depb[(size_t)d * HW], Hs, Ws, half_w, half_h);
+        const Taps t = project_taps(q, ray, depb[(size_t)d * HW], Hs, Ws);
         for (int c = 0; c < C; ++c) scatter(gsrcb + (size_t)c * HWs, t, goutb[((size_t)c * D + d) * HW]);
     }
 }

@@ -94,22 +94,22 @@ def test_fused_support_table_matches_library(lib):
 
 def test_backward_workspace_and_route_queries(lib):
     """mvster_cost_volume_bwd_workspace / _route are pure host arithmetic.  The binned route wants the coefficients
-    [B,S,HW,D,G] plus the counting sort's arrays (counts, offsets, cursor per tile; 4 tile entries per (view, pixel,
-    hypothesis) sample at worst); offering only the coefficients selects the round-1 tiled scatter where it exists;
-    planar layout or unsupported shapes want nothing."""
+    [B,S,HW,D,G] plus the counting sort's arrays (counts, offsets, cursor per bin = (tile, category); exactly ONE item
+    per (view, pixel, hypothesis) sample); offering only the coefficients selects the round-1 tiled scatter where it
+    exists; planar layout or unsupported shapes want nothing."""
     q, route = _lib.bwd_workspace, _lib.bwd_route
     NH = _lib.LAYOUT_NHWC
 
     def expected(S, B, C, G, D, H, W, Hs, Ws):
         tw, th = {8: (16, 8), 16: (16, 8), 32: (16, 8), 64: (8, 8)}[C]
-        nb = B * S * (-(-Ws // tw)) * (-(-Hs // th))
+        nb = B * S * (-(-Ws // tw)) * (-(-Hs // th)) * 4          # interior / bottom row / right column / corner
         al = lambda v: (v + 3) & ~3
         counts = al(B * S * H * W * D * G)
         partials = al(counts + nb)
         offsets = al(partials + -(-nb // 1024))
         cursor = al(offsets + nb + 1)
         items = al(cursor + nb)
-        return al(items + 4 * B * S * H * W * D)
+        return al(items + B * S * H * W * D)
 
     for args in ((4, 4, 32, 8, 8, 296, 400, 296, 400), (4, 1, 64, 8, 8, 148, 200, 148, 200), (9, 1, 16, 4, 8, 768, 1024, 768, 1024),
                  (4, 4, 8, 4, 4, 1184, 1600, 1184, 1600), (2, 3, 16, 8, 16, 33, 47, 30, 50)):
@@ -127,8 +127,10 @@ def test_backward_workspace_and_route_queries(lib):
     assert route(4, 4, 32, 8, 8, 296, 400, 296, 400, _lib.LAYOUT_NCHW, 10 ** 12)[1] == "planar"
     assert route(4, 4, 48, 8, 8, 296, 400, 296, 400, NH, 10 ** 12)[1] == "none"
     # more than 2^31 item slots: the binned route does not apply, the coefficient-only routes still do
-    assert q(16, 64, 64, 4, 8, 1184, 1600, 1184, 1600, NH) == 16 * 64 * 1184 * 1600 * 8 * 4
-    assert q(16, 64, 64, 4, 8, 1184, 1600, 1184, 1600, NH, route="binned") == -1
+    assert q(32, 64, 64, 4, 8, 1184, 1600, 1184, 1600, NH) == 32 * 64 * 1184 * 1600 * 8 * 4
+    assert q(32, 64, 64, 4, 8, 1184, 1600, 1184, 1600, NH, route="binned") == -1
+    # items name their pixel in 14 + 14 bits: maps wider than 16384 take another route
+    assert q(1, 1, 8, 4, 4, 8, 16400, 8, 16400, NH, route="binned") == -1
     assert q(4, 1, 8, 4, 4, 64, 80, 64, 80, NH, route="split_window") == -1 and q(4, 4, 8, 4, 4, 1184, 1600, 1184, 1600, NH, route="split_window") == 0
     for args in ((4, 4, 32, 8, 8, 296, 400, 296, 400, _lib.LAYOUT_NCHW), (4, 4, 48, 8, 8, 296, 400, 296, 400, NH),
                  (0, 4, 32, 8, 8, 296, 400, 296, 400, NH), (4, 4, 32, 8, 8, 0, 400, 296, 400, NH)):

@@ -295,7 +295,12 @@ def test_dtu_stage_forward_backward_vs_oracle(dev, stage):
 
     net = mv.stagenet(inverse_depth=True, mono=False, attn_fuse_d=True, attn_temp=2.0).train()
     out = net(gpu_feats, mats.to(dev), hypo.to(dev), regnet, stage, group_cor=True, group_cor_dim=G, split_itv=0.5)
-    close(seen["vol"], want_vol, 2e-5, 1e-6, "stage%d volume" % (stage + 1))
+    # float64 run of the same operator sequence = the exact arbiter (close(exact=...)): the HIP result must also be at
+    # least as close to it as the fp32 oracle is.  (On white-noise features a sample position 1e-4 px off moves the volume
+    # by ~1e-4..1e-3: the kernels therefore round the POSITION like the reference does, csrc/mvster_device.h land().)
+    exact_vol = orc.fuse_source_views([f.detach().double() for f in cpu_feats], mats.double(), hypo.double(), True, G, 2.0, True)
+    close(seen["vol"], want_vol, 2e-5, 1e-6, "stage%d volume" % (stage + 1), exact=exact_vol)
+    del exact_vol
     close(out["attn_weight"], want["attn_weight"], 0.0, 5e-5, "stage%d attn_weight" % (stage + 1))
     idx = out["attn_weight"].max(1)[1].cpu()
     match = float((idx == want["argmax_index"]).float().mean())
