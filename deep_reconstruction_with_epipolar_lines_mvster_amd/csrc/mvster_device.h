@@ -69,6 +69,16 @@ __device__ __forceinline__ float exp_nonpos(float x) {
     return fmaf(e, r * kLn2, e);
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() fences every address space: it drains the
+// wave's global loads (s_waitcnt vmcnt(0)) before the barrier, so a prefetch issued ahead of a barrier is over when the
+// barrier returns and nothing overlaps.  The LDS-only fence waits for the wave's LDS operations alone (lgkmcnt); global
+// loads, stores and atomics stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---- cross-lane: DPP ---------------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {
