@@ -42,7 +42,7 @@ struct BinArgs {
 // all views in turn.  FILL: `counters` is the cursor array (starts at the bin offsets).
 template <bool FILL, int D>
 __global__ void __launch_bounds__(kBlock)
-bin_items_kernel(BinArgs a, int* __restrict__ counters, Item* __restrict__ items) {
+bin_items_kernel(BinArgs a, int* __restrict__ counters, int* __restrict__ items) {
     constexpr int PXB = kBlock / D;
     const VolumeDims& dm = a.dm;
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
@@ -63,7 +63,7 @@ bin_items_kernel(BinArgs a, int* __restrict__ counters, Item* __restrict__ items
         int* __restrict__ view = counters + ((size_t)b * dm.S + s) * a.tiles_per_view * kBinCats;
         if constexpr (FILL) {
             const Claim c = claim_slots<0>(bf, view, l, own.live, lane, lm);
-            consume_claim<0>(bf, c, lane, make_item(item, l, a.bg));
+            consume_claim<0>(bf, c, lane, item);
         } else {
             count_sample<0>(bc, view, l, own.live, lane, lm);
         }
@@ -129,7 +129,7 @@ struct OwnerArgs {
     const float* pose;
     const float* hypo;
     const int* offsets;     // [nbins + 1], nbins = ntiles * 4
-    const Item* items;
+    const int* items;
     GradPtrs gsrcs;
     VolumeDims dm;
     BinGrid bg;
@@ -152,14 +152,12 @@ struct OwnerTile {
 // concatenation is item i + shift(i).
 struct OwnerLists {
     int n;                  // samples in all
-    int nleft;              // the first nleft come from the LEFT neighbour (they open the first stretch)
     int c0, c1, c2;         // cumulative ends of the first three stretches
     int s0, d1, d2, d3;     // shift of the first stretch, shift increments of the following ones
 };
 __device__ __forceinline__ OwnerLists owner_lists(const int* __restrict__ offsets, int tile, int tx, int ty, int tiles_x) {
     const int t4 = tile * kBinCats, u4 = t4 - tiles_x * kBinCats;
-    const int own_beg = offsets[t4];
-    const int a_beg = tx > 0 ? offsets[t4 - 2] : own_beg, a_end = offsets[t4 + 4];
+    const int a_beg = offsets[tx > 0 ? t4 - 2 : t4], a_end = offsets[t4 + 4];
     int b_beg = 0, b_end = 0, c_beg = 0, c_end = 0, d_beg = 0, d_end = 0;
     if (ty > 0) {
         c_beg = offsets[u4 + 1];            // above: bottom row
@@ -172,7 +170,6 @@ __device__ __forceinline__ OwnerLists owner_lists(const int* __restrict__ offset
         }
     }
     OwnerLists o;
-    o.nleft = own_beg - a_beg;
     o.c0 = a_end - a_beg;
     o.c1 = o.c0 + (b_end - b_beg);
     o.c2 = o.c1 + (c_end - c_beg);
@@ -185,17 +182,9 @@ __device__ __forceinline__ OwnerLists owner_lists(const int* __restrict__ offset
     return o;
 }
 // (written with arithmetic on the comparison results: a chain of selects on four values becomes a lookup table in scratch)
-__device__ __forceinline__ Item owner_item(const Item* __restrict__ items, const OwnerLists& o, int i) {
+__device__ __forceinline__ int owner_item(const int* __restrict__ items, const OwnerLists& o, int i) {
     const int shift = o.s0 + (i >= o.c0 ? o.d1 : 0) + (i >= o.c1 ? o.d2 : 0) + (i >= o.c2 ? o.d3 : 0);
     return items[i + shift];
-}
-// cell (0 .. NCELL-1) of item number i in the OWNER's frame of (TW+1) x (TH+1) upper-left positions: an item carries its
-// position relative to its home tile; seen from the right / lower neighbour the home tile's last column / row is cell 0
-template <int TW, int TH>
-__device__ __forceinline__ int owner_cell(const OwnerLists& o, int i, int where) {
-    const bool from_up = i >= o.c0, from_left = i < o.nleft || (from_up && i < o.c1);
-    const int cx = (where & 0xFF) - (from_left ? TW : 0), cy = ((where >> 8) & 0xFF) - (from_up ? TH : 0);
-    return ((unsigned)cx <= (unsigned)TW && (unsigned)cy <= (unsigned)TH) ? cy * (TW + 1) + cx : -1;
 }
 
 struct __attribute__((aligned(16))) SampleRec {
@@ -236,6 +225,8 @@ tile_owner_kernel(OwnerArgs a) {
 
     const OwnerLists lists = owner_lists(a.offsets, bin, tx, ty, a.bg.tiles_x);
     const int n = lists.n;
+    const Pose q = load_pose(a.pose + ((size_t)b * dm.S + s) * 12);
+    const float* __restrict__ hypo = a.hypo + (size_t)b * D * HW;
     const float* __restrict__ dcor = a.dcor + ((size_t)b * dm.S + s) * HW * D * G;
     const float* __restrict__ ref = a.ref + (size_t)b * HW * C;
 
@@ -251,15 +242,20 @@ tile_owner_kernel(OwnerArgs a) {
             const int i = tid + j * NT;
             cell[j] = -1;
             if (i < m) {
-                const Item it = owner_item(a.items, lists, c0 + i);
+                const int id = owner_item(a.items, lists, c0 + i);
                 int x, y, d;
-                unpack_item(it.id, x, y, d);
-                rec[j].id = (__mul24(y, dm.W) + x) * D + d;
-                rec[j].mask = (it.where >> 16) & 0xF;
-                rec[j].fx = it.fx;
-                rec[j].fy = it.fy;
-                cell[j] = owner_cell<TW, TH>(lists, c0 + i, it.where);
-                if (cell[j] >= 0) slot[j] = atomicAdd(&cnt[cell[j]], 1);
+                unpack_item(id, x, y, d);
+                const int p = __mul24(y, dm.W) + x;
+                const Landing l = land(q, rotate_pixel(q, (float)x, (float)y), hypo[(size_t)d * HW + p], dm.Hs, dm.Ws);
+                const int cx = l.ix - x0 + 1, cy = l.iy - y0 + 1;
+                rec[j].id = p * D + d;
+                rec[j].mask = landing_mask(l);
+                rec[j].fx = l.fx;
+                rec[j].fy = l.fy;
+                if ((unsigned)cx < (unsigned)BW && (unsigned)cy < (unsigned)T::BH) {     // always, for a sample listed here
+                    cell[j] = cy * BW + cx;
+                    slot[j] = atomicAdd(&cnt[cell[j]], 1);
+                }
             }
         }
         lds_barrier();
@@ -423,6 +419,8 @@ tile_owner_c8_kernel(OwnerArgs a) {
 
     const OwnerLists lists = owner_lists(a.offsets, bin, tx, ty, a.bg.tiles_x);
     const int n = lists.n;
+    const Pose q = load_pose(a.pose + ((size_t)b * dm.S + s) * 12);
+    const float* __restrict__ hypo = a.hypo + (size_t)b * D * HW;
     const float* __restrict__ dcor = a.dcor + ((size_t)b * dm.S + s) * HW * D * G;
     const float* __restrict__ ref = a.ref + (size_t)b * HW * C;
 
@@ -432,25 +430,28 @@ tile_owner_c8_kernel(OwnerArgs a) {
 #pragma unroll
         for (int c = 0; c < C / 2; ++c) acc[k][c] = f32x2{0.0f, 0.0f};
 
-    // the items of the NEXT chunk are requested while this chunk's data is in flight
-    Item it_next[KPT];
+    // the items of the NEXT chunk are requested while this chunk's data is in flight: one dependent round trip per
+    // chunk instead of two
+    int id_next[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const int i = tid + j * NT;
-        it_next[j] = i < n ? owner_item(a.items, lists, i) : Item{-1, 0, 0.0f, 0.0f};
+        id_next[j] = i < n ? owner_item(a.items, lists, i) : -1;
     }
     for (int c0 = 0; c0 < n; c0 += CHUNK) {
         cnt[tid] = 0;
         lds_barrier();
         // ---- fetch: everything that depends on the items, all in flight together ---------------------------------------
-        Item it[KPT];
+        int id[KPT], px[KPT], py[KPT];
+        float hyp[KPT];
         float4 cf0[KPT], cf1[KPT], r0[KPT], r1[KPT];
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
-            it[j] = it_next[j];
-            int x, y, d;
-            unpack_item(max(it[j].id, 0), x, y, d);
-            const int p = __mul24(y, dm.W) + x;
+            id[j] = id_next[j];
+            int d;
+            unpack_item(max(id[j], 0), px[j], py[j], d);
+            const int p = __mul24(py[j], dm.W) + px[j];
+            hyp[j] = hypo[(size_t)d * HW + p];
             const float4* __restrict__ cp = reinterpret_cast<const float4*>(dcor + ((size_t)p * D + d) * G);
             cf0[j] = cp[0];
             if constexpr (G == 8) cf1[j] = cp[1];
@@ -461,23 +462,27 @@ tile_owner_c8_kernel(OwnerArgs a) {
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const int i = c0 + CHUNK + tid + j * NT;
-            it_next[j] = i < n ? owner_item(a.items, lists, i) : Item{-1, 0, 0.0f, 0.0f};
+            id_next[j] = i < n ? owner_item(a.items, lists, i) : -1;
         }
-        // ---- the sample's record, count per owner ----------------------------------------------------------------------
+        // ---- project, count per owner ----------------------------------------------------------------------------------
         StagedRec rec[KPT];
         int cell[KPT], slot[KPT];
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             cell[j] = -1;
-            if (it[j].id >= 0) {
-                weights_from_fraction(it[j].fx, it[j].fy, (it[j].where >> 16) & 0xF, rec[j].w);
+            if (id[j] >= 0) {
+                const Landing l = land(q, rotate_pixel(q, (float)px[j], (float)py[j]), hyp[j], dm.Hs, dm.Ws);
+                const int cx = l.ix - x0 + 1, cy = l.iy - y0 + 1;
+                weights_from_fraction(l.fx, l.fy, landing_mask(l), rec[j].w);
                 const float rv[C] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w, r1[j].x, r1[j].y, r1[j].z, r1[j].w};
                 const float cf[8] = {cf0[j].x, cf0[j].y, cf0[j].z, cf0[j].w, G == 8 ? cf1[j].x : 0.0f, G == 8 ? cf1[j].y : 0.0f,
                                      G == 8 ? cf1[j].z : 0.0f, G == 8 ? cf1[j].w : 0.0f};
 #pragma unroll
                 for (int c = 0; c < C; ++c) rec[j].dw[c] = cf[c / CPG] * rv[c];
-                cell[j] = owner_cell<TW, TH>(lists, c0 + tid + j * NT, it[j].where);
-                if (cell[j] >= 0) slot[j] = atomicAdd(&cnt[cell[j]], 1);
+                if ((unsigned)cx < (unsigned)BW && (unsigned)cy < (unsigned)T::BH) {
+                    cell[j] = cy * BW + cx;
+                    slot[j] = atomicAdd(&cnt[cell[j]], 1);
+                }
             }
         }
         lds_barrier();
@@ -577,7 +582,7 @@ static int launch_owner(const OwnerArgs& a, int D, hipStream_t st) {
 }
 
 template <bool FILL>
-static int launch_bin_items(const BinArgs& ba, int B, int D, int* counters, Item* items, hipStream_t st) {
+static int launch_bin_items(const BinArgs& ba, int B, int D, int* counters, int* items, hipStream_t st) {
     BinArgs a = ba;
     auto launch = [&](auto dtag) {
         constexpr int DD = decltype(dtag)::value;
@@ -610,7 +615,7 @@ int launch_binned_scatter(const float* ref, const float* pose, const float* hypo
     int* const counts = words + lay.counts;
     int* const offsets = words + lay.offsets;
     int* const cursor = words + lay.cursor;
-    Item* const items = reinterpret_cast<Item*>(words + lay.items);
+    int* const items = words + lay.items;
     const int nbins = (int)lay.nbins;
     if (!items_filled) {                   // stand-alone counting sort: the forward pass did not count for us
         if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)nbins, st) != hipSuccess) {

@@ -436,19 +436,16 @@ cost_volume_bwd_coef_kernel(const float* __restrict__ gvol, const float* __restr
     const LaneMasks lm = lane_masks(lane);
     const int item = pack_item(own.x, own.y, d);
     __shared__ BinAgg agg;
-    __shared__ int4 stash[kAggViews][kBlock];       // per (view of the batch, thread): place, item.where, item.fx, item.fy
+    __shared__ int places[kAggViews][kBlock];
     const bool filling = bf.cursor != nullptr;
     if (filling) agg_reset(agg);
     for (int s = 0; s < dm.S; ++s) {
         const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C;
         const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
         const Landing l = land(q, rotate_pixel(q, fx, fy), hyp, dm.Hs, dm.Ws);
-        int* __restrict__ view_cursor = filling ? bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view * kBinCats : nullptr;
-        if (filling) {                                                           // wave-uniform
-            const int place = agg_claim<0>(agg, s % kAggViews, bf, view_cursor, l, live, lane, lm, item);
-            const Item it = make_item(item, l, bf.bg);
-            stash[s % kAggViews][threadIdx.x] = make_int4(place, it.where, __float_as_int(it.fx), __float_as_int(it.fy));
-        }
+        if (filling)                                                             // wave-uniform
+            places[s % kAggViews][threadIdx.x] = agg_claim<0>(agg, s % kAggViews, bf, bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view * kBinCats,
+                                                              l, live, lane, lm, item);
         unsigned o[4];
         float w4[4];
         tap_addresses<C>(l, dm.Hs, dm.Ws, o, w4);
@@ -483,10 +480,7 @@ cost_volume_bwd_coef_kernel(const float* __restrict__ gvol, const float* __restr
         }
         if (filling && (s % kAggViews == kAggViews - 1 || s == dm.S - 1)) {      // the batch's slots: one claim per occupied entry
             agg_flush_claims(agg, bf.cursor, bf.tiles_per_view * kBinCats, b, dm.S, s - s % kAggViews);
-            for (int v = 0; v <= s % kAggViews; ++v) {
-                const int4 st = stash[v][threadIdx.x];
-                agg_write_item<0>(agg, v, bf, st.x, lane, Item{item, st.y, __int_as_float(st.z), __int_as_float(st.w)});
-            }
+            for (int v = 0; v <= s % kAggViews; ++v) agg_write_item<0>(agg, v, bf, places[v][threadIdx.x], lane, item);
         }
     }
     // reference gradient: sum over the D hypothesis lanes of the pixel, lane d stores channels [d C/D', ...)
@@ -754,19 +748,16 @@ cost_volume_bwd_coef_split_kernel(const float* __restrict__ gvol, const float* _
     const LaneMasks lm = lane_masks(lane);
     const int item = pack_item(x, y, d);
     __shared__ BinAgg agg;
-    __shared__ int4 stash[kAggViews][kBlock];       // per (view of the batch, thread): place, item.where, item.fx, item.fy
+    __shared__ int places[kAggViews][kBlock];
     const bool filling = bf.cursor != nullptr;
     if (filling) agg_reset(agg);
     for (int s = 0; s < dm.S; ++s) {
         const float* __restrict__ srcb = srcs.p[s] + (size_t)b * HWs * C + h * CL;
         const Pose q = load_pose(pose + ((size_t)b * dm.S + s) * 12);
         const Landing l = land(q, rotate_pixel(q, (float)x, (float)y), hyp, dm.Hs, dm.Ws);
-        int* __restrict__ view_cursor = filling ? bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view * kBinCats : nullptr;
-        if (filling) {                                                           // wave-uniform
-            const int place = agg_claim<HSLOG>(agg, s % kAggViews, bf, view_cursor, l, live, lane, lm, item);
-            const Item it = make_item(item, l, bf.bg);
-            stash[s % kAggViews][threadIdx.x] = make_int4(place, it.where, __float_as_int(it.fx), __float_as_int(it.fy));
-        }
+        if (filling)                                                             // wave-uniform
+            places[s % kAggViews][threadIdx.x] = agg_claim<HSLOG>(agg, s % kAggViews, bf, bf.cursor + ((size_t)b * dm.S + s) * bf.tiles_per_view * kBinCats,
+                                                                  l, live, lane, lm, item);
         unsigned o[4];
         float w4[4];
         tap_addresses<C>(l, dm.Hs, dm.Ws, o, w4);
@@ -802,12 +793,9 @@ cost_volume_bwd_coef_split_kernel(const float* __restrict__ gvol, const float* _
             else if constexpr (GL == 2) *reinterpret_cast<float2*>(out) = make_float2(coef[0], coef[1]);
             else out[0] = coef[0];
         }
-        if (filling && (s % kAggViews == kAggViews - 1 || s == dm.S - 1)) {      // the batch's slots: one claim per occupied entry
+        if (filling && (s % kAggViews == kAggViews - 1 || s == dm.S - 1)) {
             agg_flush_claims(agg, bf.cursor, bf.tiles_per_view * kBinCats, b, dm.S, s - s % kAggViews);
-            for (int v = 0; v <= s % kAggViews; ++v) {
-                const int4 st = stash[v][threadIdx.x];
-                agg_write_item<HSLOG>(agg, v, bf, st.x, lane, Item{item, st.y, __int_as_float(st.z), __int_as_float(st.w)});
-            }
+            for (int v = 0; v <= s % kAggViews; ++v) agg_write_item<HSLOG>(agg, v, bf, places[v][threadIdx.x], lane, item);
         }
     }
     // reference gradient: sum over the D hypothesis lanes of this channel part
@@ -851,7 +839,7 @@ static int launch_bwd_deferred(const float* gvol, const float* vol, const float*
         if (int rc = launch_bin_scan(fwd_counts, workspace, lay, st)) return rc;
         int* const words = reinterpret_cast<int*>(workspace);
         bf.cursor = words + lay.cursor;
-        bf.items = reinterpret_cast<Item*>(words + lay.items);
+        bf.items = words + lay.items;
         bf.bg = bin_grid_for(CPG * G, dm.Hs, dm.Ws);
         bf.tiles_per_view = bf.bg.tiles_x * bf.bg.tiles_y;
         bf.max_items = (int)lay.max_items;

@@ -229,22 +229,14 @@ inline BinGrid bin_grid_for(int C, int Hs, int Ws) {
     return g;
 }
 
-// An item (16 bytes) carries what the owner of its destination needs of the sample, so that the owner neither projects
-// it again nor gathers its hypothesis: id = reference pixel (x, y) and hypothesis d packed as y << 18 | x << 4 | d (no integer
-// division by the run-time image width when it is unpacked); where = upper-left tap relative to the sample's home tile
-// (hx + 1 in bits 0-7, hy + 1 in bits 8-15) and the in-map bits of its four taps (bits 16-19); fx, fy = the fractional
-// position, bit for bit what the forward pass interpolated with.
+// An item names its sample: reference pixel (x, y) and hypothesis d packed as y << 18 | x << 4 | d (no integer division
+// by the run-time image width when it is unpacked).
 constexpr int kItemXBits = 14, kItemDBits = 4;
 constexpr int kMaxItemDim = 1 << kItemXBits;       // H, W <= 16384, D <= 16
-constexpr int kItemWords = 4;
-struct __attribute__((aligned(16))) Item {
-    int id, where;
-    float fx, fy;
-};
 
 // Workspace of the binned route, in 4-byte words: per-hypothesis group coefficients [B,S,HW,D,G] (float), then the
 // counting sort's arrays (int): counts[nbins], partials[nbins / 1024 rounded up] (scan), offsets[nbins + 1], cursor[nbins],
-// items[B*S*HW*D] of 16 bytes -- exactly one item per (sample, view).
+// items[B*S*HW*D] -- exactly one item per (sample, view).
 struct BinnedLayout {
     long long coef, counts, partials, offsets, cursor, items, total;     // word offsets; total = words needed
     long long nbins, max_items;
@@ -275,7 +267,7 @@ inline bool binned_layout(int S, int B, int C, int G, int D, int H, int W, int H
     l.offsets = align4(l.partials + (l.nbins + 1023) / 1024);
     l.cursor = align4(l.offsets + l.nbins + 1);
     l.items = align4(l.cursor + l.nbins);
-    l.total = align4(l.items + kItemWords * l.max_items);
+    l.total = align4(l.items + l.max_items);
     if (out != nullptr) *out = l;
     return true;
 }
@@ -301,7 +293,7 @@ struct BinCount {            // forward: counters[((b*S + s) * tiles_per_view + 
 };
 struct BinFill {             // backward coefficient kernel: claim slots from cursor[] (starts at the bin offsets), write items
     int* cursor;             // nullptr: do not fill
-    Item* items;
+    int* items;
     BinGrid bg;
     int tiles_per_view;
     int max_items;           // capacity of items[]: a stale or foreign counts buffer cannot make the fill write past it
@@ -312,17 +304,6 @@ __device__ __forceinline__ void unpack_item(int item, int& x, int& y, int& d) {
     d = item & ((1 << kItemDBits) - 1);
     x = (item >> kItemDBits) & (kMaxItemDim - 1);
     y = (int)((unsigned)item >> (kItemXBits + kItemDBits));
-}
-
-__device__ __forceinline__ Item make_item(int id, const Landing& l, const BinGrid& bg) {
-    const int xc = max(l.ix, 0), yc = max(l.iy, 0);
-    const int hx1 = l.ix - ((xc >> bg.lw) << bg.lw) + 1, hy1 = l.iy - ((yc >> bg.lh) << bg.lh) + 1;    // 0 .. tile width / height
-    Item it;
-    it.id = id;
-    it.where = hx1 | (hy1 << 8) | (landing_mask(l) << 16);
-    it.fx = l.fx;
-    it.fy = l.fy;
-    return it;
 }
 
 // Bin (within one (batch, view)) of a sample; listed = at least one tap inside the map and the position finite.
@@ -408,7 +389,7 @@ __device__ __forceinline__ Claim claim_slots(const BinFill& bf, int* __restrict_
     return c;
 }
 template <int HSLOG = 0>
-__device__ __forceinline__ void consume_claim(const BinFill& bf, const Claim& c, int lane, const Item& item) {
+__device__ __forceinline__ void consume_claim(const BinFill& bf, const Claim& c, int lane, int item) {
     const int slot = __shfl(c.base, c.head_lane, kWave) + ((lane - c.head_lane) >> HSLOG);
     const bool first = (lane & ((1 << HSLOG) - 1)) == 0;
     if (c.listed && first && (unsigned)slot < (unsigned)bf.max_items) bf.items[slot] = item;
@@ -469,7 +450,7 @@ __device__ __forceinline__ void agg_flush_counts(BinAgg& t, int* __restrict__ co
 // when the sample is not listed (or was written already: table collision, handled on the spot).
 template <int HSLOG = 0>
 __device__ __forceinline__ int agg_claim(BinAgg& t, int v, const BinFill& bf, int* __restrict__ view_cursor, const Landing& l,
-                                         bool live, int lane, const LaneMasks& lm, int id) {
+                                         bool live, int lane, const LaneMasks& lm, int item) {
     bool listed;
     int entry;
     const int bin = sample_bin(l, bf.bg, listed, entry);
@@ -485,7 +466,7 @@ __device__ __forceinline__ int agg_claim(BinAgg& t, int v, const BinFill& bf, in
         c.base = place == -2 ? atomicAdd(view_cursor + bin, r.len >> HSLOG) : 0;
         c.head_lane = r.head_lane;
         c.listed = listed && __shfl(place, r.head_lane, kWave) == -2;
-        consume_claim<HSLOG>(bf, c, lane, make_item(id, l, bf.bg));
+        consume_claim<HSLOG>(bf, c, lane, item);
     }
     const int head_place = __shfl(place, r.head_lane, kWave);
     return (listed && head_place >= 0) ? head_place + ((lane - r.head_lane) >> HSLOG) : -1;
@@ -505,7 +486,7 @@ __device__ __forceinline__ void agg_flush_claims(BinAgg& t, int* __restrict__ cu
     lds_barrier();
 }
 template <int HSLOG = 0>
-__device__ __forceinline__ void agg_write_item(const BinAgg& t, int v, const BinFill& bf, int place, int lane, const Item& item) {
+__device__ __forceinline__ void agg_write_item(const BinAgg& t, int v, const BinFill& bf, int place, int lane, int item) {
     const bool first = (lane & ((1 << HSLOG) - 1)) == 0;
     if (place >= 0 && first) {
         const int slot = t.bases[v][place >> 16] + (place & 0xFFFF);

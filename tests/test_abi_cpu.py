@@ -95,7 +95,7 @@ def test_fused_support_table_matches_library(lib):
 def test_backward_workspace_and_route_queries(lib):
     """mvster_cost_volume_bwd_workspace / _route are pure host arithmetic.  The binned route wants the coefficients
     [B,S,HW,D,G] plus the counting sort's arrays (counts, offsets, cursor per bin = (tile, category); exactly ONE item
-    of 16 bytes per (view, pixel, hypothesis) sample); offering only the coefficients selects the round-1 tiled scatter where it
+    per (view, pixel, hypothesis) sample); offering only the coefficients selects the round-1 tiled scatter where it
     exists; planar layout or unsupported shapes want nothing."""
     q, route = _lib.bwd_workspace, _lib.bwd_route
     NH = _lib.LAYOUT_NHWC
@@ -109,7 +109,7 @@ def test_backward_workspace_and_route_queries(lib):
         offsets = al(partials + -(-nb // 1024))
         cursor = al(offsets + nb + 1)
         items = al(cursor + nb)
-        return al(items + 4 * B * S * H * W * D)          # 16-byte items
+        return al(items + B * S * H * W * D)
 
     for args in ((4, 4, 32, 8, 8, 296, 400, 296, 400), (4, 1, 64, 8, 8, 148, 200, 148, 200), (9, 1, 16, 4, 8, 768, 1024, 768, 1024),
                  (4, 4, 8, 4, 4, 1184, 1600, 1184, 1600), (2, 3, 16, 8, 16, 33, 47, 30, 50)):
