@@ -11,7 +11,8 @@ shapes (1600x1184, 1 ref + 4 src views, D = 8,8,4,4, G = 8,8,4,4; SURVEY.md sect
 
   per stage: hypothesis scheduling (A5/A6) -> poses -> fused cost volume (A2) -> stub regnet (vol.sum(1), the
   callback the reference's reg2d occupies; out of scope) -> depth regression (A4); loss = sum(attn * w);
-  backward: softmax backward -> stub regnet backward -> fused cost-volume backward (A3, fp32 atomics).
+  backward: softmax backward -> stub regnet backward -> fused cost-volume backward (A3: coefficient kernel + counting sort
+  by destination tile + owner kernels, no float atomics).
 
 Every rank works on its own batch (units = reference views, no data-path collective).  With more than one rank
 the step carries the only exchange the reference has in training, DDP's gradient all-reduce (train_mvs4.py:562-570):
@@ -24,6 +25,8 @@ Prints ONE JSON line on rank 0 (see README / the driver contract) with two extra
                   launch stream, collected over the timed steps) against the 8 TB/s HBM peak;
   cpu_baseline -- the CPU oracle (same torch operator sequence as the reference's CPU path, kind "port")
                   timed on this host's cores on a bounded sample (one reference view; 1 warm-up + 3 timed passes, median).
+  e2e          -- after the timed region: the drop-in MVS4net shell's training step (forward, MVS4net_loss ot_iter = 10,
+                  backward, Adam) and inference forward at 1600x1152, N = 5, eager and as one HIP graph (--no-e2e skips it).
 """
 import argparse
 import hashlib
@@ -488,6 +491,143 @@ class GradientExchange:
         self.work.clear()
 
 
+# ---------------------------------------------------------------------------------- end-to-end step (SURVEY 8d ii)
+FP32_MATRIX_PEAK_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32 / vector fp32, MI355X (MI355X_MICROARCH.md)
+
+
+def conv_flops(name, a):
+    """FLOPs of one convolution C-ABI call from its arguments (include/mvster_hip.h); 0 for every other entry."""
+    if name == "mvster_conv_mfma_fwd":
+        N, Cin, Cout, H, W, K, st = a[6:13]
+        return 2.0 * N * Cin * Cout * K * K * (H // st) * (W // st)
+    if name == "mvster_conv_mfma_wgrad":
+        N, Cin, Cout, H, W, K, st = a[5:12]
+        return 2.0 * N * Cin * Cout * K * K * (H // st) * (W // st)
+    if name == "mvster_conv_mfma_depth3_fwd":
+        N, C, Cout, H, W, K = a[6:12]
+        return 2.0 * N * 3 * C * Cout * K * K * H * W
+    if name == "mvster_conv_mfma_depth3_wgrad":
+        N, C, Cout, H, W, K = a[5:11]
+        return 2.0 * N * 3 * C * Cout * K * K * H * W
+    if name == "mvster_conv_mfma_transposed":
+        N, Cin, Cout, H, W = a[5:10]
+        return 2.0 * N * Cin * Cout * a[12] * a[12] * H * W
+    if name == "mvster_conv_direct_fwd":
+        N, Cin, Cout, H, W, K = a[4:10]
+        return 2.0 * N * Cin * Cout * K * K * H * W
+    if name == "mvster_conv_direct_wgrad":
+        N, Cin, Cout, H, W, K = a[6:12]
+        return 2.0 * N * Cin * Cout * K * K * H * W
+    return 0.0
+
+
+def e2e_measure(device, steps=5, height=1152, width=1600, views=5, batches=(1, 4)):
+    """The reference's training step (train_mvs4.py:314,335,344: forward, MVS4net_loss with ot_iter = 10, backward, Adam) and
+    its inference forward (test_mvs4.py:408-415) on the drop-in MVS4net shell at 1600x1152 (1184 is illegal for reg2d,
+    SURVEY 8d), random-init weights, synthetic images: eager and as one HIP graph.  Informational: the headline metric is
+    the hot path above.  Returns the `e2e` object of the JSON line."""
+    from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net as _m
+    torch.backends.cudnn.benchmark = False
+    H, W, N = height, width, views
+    out = {"shape": "%dx%d, N=%d views (1 ref + %d src), D=(8,8,4,4), G=(8,8,4,4), inverse depth, mono head, Adam, fp32" % (W, H, N, N - 1),
+           "note": "end-to-end MVS4net shell; eager = ~1400 kernel launches issued from Python, graph = the same step as one HIP graph"}
+    orig_call = _lib.call
+    for B in batches:
+        torch.manual_seed(0)
+        model = mv.MVS4net(arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8,
+                           stage_splits=[8, 8, 4, 4], depth_interals_ratio=[0.5, 0.5, 0.5, 1], group_cor=True,
+                           group_cor_dim=[8, 8, 4, 4], inverse_depth=True, mono=True, attn_temp=2).to(device)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        imgs = [torch.rand(B, 3, H, W, device=device) for _ in range(N)]
+        proj = {"stage%d" % (k + 1): synth_views(B, N, H // sc, W // sc).to(device) for k, sc in enumerate((8, 4, 2, 1))}
+        dv = torch.tensor([list(DEPTH_RANGE)] * B, device=device)
+        gts = {"stage%d" % (k + 1): 480 + 400 * torch.rand(B, H // sc, W // sc, device=device) for k, sc in enumerate((8, 4, 2, 1))}
+        masks = {k: (torch.rand_like(v) < 0.7).float() for k, v in gts.items()}
+        kw = dict(stage_lw=[1, 1, 1, 1], l1ot_lw=[0, 1], inverse_depth=True, ot_iter=10, ot_eps=1, ot_continous=False, mono=True)
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            loss = mv.MVS4net_loss(model(imgs, proj, dv), gts, masks, **kw)[0]
+            loss.backward()
+            opt.step()
+
+        def eval_step():
+            with torch.no_grad():
+                return model(imgs, proj, dv)["stage4"]["depth"]
+
+        def timed(step):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(device)
+            return 1e3 * (time.perf_counter() - t0) / steps
+
+        def as_graph(step, train):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                    # allocator warm-up on the capture side stream
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(device)
+            graph = torch.cuda.CUDAGraph()
+            if train:
+                opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                step()
+            graph.replay()
+            return graph.replay
+
+        for mode, step in (("train", train_step), ("eval", eval_step)):
+            if mode == "eval" and B != batches[0]:
+                continue                                     # inference runs one reference view at a time (test_mvs4.py:947)
+            model.train(mode == "train")
+            torch.cuda.reset_peak_memory_stats(device)
+            step()
+            step()
+            # one instrumented eager step: C-ABI launches and the convolutions' share (HIP events around each call)
+            calls, conv = [0], []
+
+            def counted(name, *a):
+                calls[0] += 1
+                fl = conv_flops(name, a)
+                if fl == 0.0:
+                    return orig_call(name, *a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = orig_call(name, *a)
+                e1.record()
+                conv.append((fl, e0, e1))
+                return r
+
+            _lib.call = _m._lib.call = mv.hotpath._lib.call = counted
+            try:
+                step()
+                torch.cuda.synchronize(device)
+            finally:
+                _lib.call = _m._lib.call = mv.hotpath._lib.call = orig_call
+            conv_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in conv)
+            conv_tf = sum(fl for fl, _, _ in conv) / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
+            eager = timed(step)
+            rec = {"eager_ms": round(eager, 2)}
+            try:
+                replay = as_graph(step, mode == "train")
+                rec["graph_ms"] = round(timed(replay), 2)
+            except Exception as exc:                           # noqa: BLE001 -- report, keep the bench line alive
+                rec["graph_ms"] = None
+                rec["graph_error"] = str(exc)[:200]
+            best = min(v for v in (rec["eager_ms"], rec.get("graph_ms")) if v)
+            rec.update({"ref_views_per_s": round(B / (best * 1e-3), 2), "peak_mem_GB": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+                        "hip_abi_calls_per_step": calls[0], "conv_ms_eager": round(conv_ms, 2),
+                        "conv_TFLOPs": round(conv_tf, 1) if conv_tf else None,
+                        "conv_frac_of_fp32_matrix_peak": round(conv_tf / FP32_MATRIX_PEAK_TFLOPS, 3) if conv_tf else None})
+            out["%s_B%d" % (mode, B)] = rec
+        del model, opt, imgs, gts, masks
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -495,6 +635,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="reference views per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end MVS4net step timed after the headline region")
     ap.add_argument("--data", default="noise", choices=["noise", "scene"],
                     help="noise: N(0,1) features (SURVEY 8d; spatially random depth, worst case for gather/scatter); "
                          "scene: multi-view-consistent textured surface (smooth depth like real data)")
@@ -586,7 +727,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic" if args.data == "noise" else "synthetic (multi-view-consistent scene features)",
             "scope": "hot path only: the regnet callback is a stub (reg2d is illegal at H=1184, SURVEY 8d); the end-to-end "
-                     "training step is measured by tools/e2e_bench.py (DESIGN.md section 5)",
+                     "training / inference step at 1600x1152 is in the `e2e` object (measured after the timed region)",
             "config": {"workload": ("MVSTER cost-volume hot path fwd+bwd (stub regnet), DTU 1600x1184 stage shapes "
                                     "148x200/296x400/592x800/1184x1600, 1 ref + 4 src views, D=(8,8,4,4), G=(8,8,4,4), "
                                     "C=(64,32,16,8), inverse depth, attn_temp 2") if other is None else
@@ -605,13 +746,9 @@ def main():
                                             "halving verified on kernels with known byte counts); source fingerprint matches")
                          if traffic_src else None,
                          "traffic_null_reason": why,
-                         "atomic_requests_per_launch": pmc and pmc.get("TCC_EA0_ATOMIC_sum_avg"),
-                         # the backward is bound by the chip-wide float-atomic REQUEST rate (64-byte requests executed at
-                         # the memory side: 1.3 TB/s / 64 B, MI355X_MICROARCH.md "Global float atomics"), not by HBM bytes
-                         "atomic_bound": pmc and pmc.get("TCC_EA0_ATOMIC_sum_avg") and {
-                             "achieved_Greq_s": round(pmc["TCC_EA0_ATOMIC_sum_avg"] / (dom["avg_ms"] * 1e-3) / 1e9, 2),
-                             "peak_Greq_s": round(1300.0 / 64.0, 2),
-                             "frac": round(pmc["TCC_EA0_ATOMIC_sum_avg"] / (dom["avg_ms"] * 1e-3) / 1e9 / (1300.0 / 64.0), 3)},
+                         # integer slot claims of the counting sort (one per occupied LDS table entry per workgroup); the
+                         # backward issues no float atomics
+                         "int_atomic_requests_per_launch": pmc and pmc.get("TCC_EA0_ATOMIC_sum_avg"),
                          "kernel": "%s = %s [B%d C%d G%d D%d px%d S%d]" % (dom["entry"], symbol.replace(";", " + "), dom["B"],
                                                                           dom["C"], dom["G"], dom["D"], dom["HW"], dom["S"]),
                          "note": "achieved / avg_launch_ms are the whole entry (all kernels of the route, HIP events around the "
@@ -620,6 +757,14 @@ def main():
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]},
             "kernels": kernels,
         }
+        if world == 1 and not args.no_e2e and other is None:
+            # after and outside the timed region; frees the hot-path inputs first
+            stages.clear()
+            torch.cuda.empty_cache()
+            try:
+                out["e2e"] = e2e_measure(device)
+            except Exception as exc:                               # noqa: BLE001 -- the headline line must survive
+                out["e2e"] = {"error": str(exc)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

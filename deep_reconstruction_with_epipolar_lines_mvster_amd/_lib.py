@@ -52,6 +52,8 @@ PROTOTYPES = {
     "mvster_bn_train_bwd_grouped": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_bn_train_fwd_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _f, _i, _vp],
     "mvster_bn_train_bwd_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp],
+    "mvster_bn_eval_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "mvster_bn_eval_fwd_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _i, _vp],
     "mvster_fpn_merge_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_fpn_merge_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_fpn_head_gather_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],

@@ -375,6 +375,22 @@ __global__ void bn_finalize_nhwc_kernel(const float* __restrict__ x, const doubl
     affine[2 * c + 1] = b;
 }
 
+// ---- inference mode ----------------------------------------------------------------------------------------------------
+// y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta (+ReLU, + residual): the statistics are constants, so the
+// layer is ONE streaming pass -- a per-channel affine prepared by a C-thread launch, then the training path's apply kernel.
+// (F.batch_norm + a separate F.relu are two passes on MIOpen / ATen; the reference's whole inference path runs in this mode,
+// test_mvs4.py:393-411.)
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float* __restrict__ affine, float* __restrict__ mean_out, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float g = gamma != nullptr ? gamma[c] : 1.0f, b = beta != nullptr ? beta[c] : 0.0f;
+    affine[2 * c] = g * (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+    affine[2 * c + 1] = b;
+    mean_out[c] = running_mean[c];
+}
+
 static int check_bn_nhwc(long long M, int C) {
     MVSTER_REQUIRE_SHAPE(M > 0 && M <= (1LL << 31) - 1 && C > 0);
     if (C % 4 != 0 || C > 64 || 64 % (C / 4) != 0) return MVSTER_ERR_UNSUPPORTED;    // C in {4, 8, 16, 32, 64}
@@ -484,5 +500,44 @@ extern "C" int mvster_bn_train_bwd_nhwc(const float* dy, const float* x, const f
         hipLaunchKernelGGL((bn_bwd_stats_nhwc_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, (int)M, C);
         hipLaunchKernelGGL((bn_bwd_apply_nhwc_kernel<false>), grid, dim3(kBlock), 0, st, dy, x, affine, save_mean, save_invstd, sums, dx, dgamma, dbeta, (int)M, C, (double)M);
     }
+    return launch_status();
+}
+
+// Inference-mode BatchNorm (+ReLU, + residual added after it) with the module's running statistics.  scratch: 3 * C floats
+// (the per-channel affine and mean the apply pass reads); replaces F.batch_norm(training=False) + F.relu
+// (models/mvs4net_utils.py:123-130,230-256 under model.eval()).
+extern "C" int mvster_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, const float* residual, float* y, float* scratch, int N, int C,
+                                  int HW, float eps, int relu, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(running_mean); MVSTER_REQUIRE_PTR(running_var);
+    MVSTER_REQUIRE_PTR(scratch);
+    if (int rc = check_bn(N, C, HW)) return rc;
+    const hipStream_t st = as_stream(stream);
+    float* const affine = scratch;
+    float* const mean = scratch + 2 * (size_t)C;
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(grid_for(C, 64)), dim3(64), 0, st, gamma, beta, running_mean, running_var, affine,
+                       mean, C, eps);
+    dim3 grid(grid_for(HW, kBlock * kBnVec * kBnIters), C, N);
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true>), grid, dim3(kBlock), 0, st, x, affine, mean, residual, y, C, HW, N);
+    else hipLaunchKernelGGL((bn_apply_kernel<false>), grid, dim3(kBlock), 0, st, x, affine, mean, residual, y, C, HW, N);
+    return launch_status();
+}
+
+extern "C" int mvster_bn_eval_fwd_nhwc(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                                       const float* running_var, float* y, float* scratch, long long M, int C, float eps,
+                                       int relu, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(running_mean); MVSTER_REQUIRE_PTR(running_var);
+    MVSTER_REQUIRE_PTR(scratch);
+    if (int rc = check_bn_nhwc(M, C)) return rc;
+    const hipStream_t st = as_stream(stream);
+    float* const affine = scratch;
+    float* const mean = scratch + 2 * (size_t)C;
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(grid_for(C, 64)), dim3(64), 0, st, gamma, beta, running_mean, running_var, affine,
+                       mean, C, eps);
+    dim3 grid(grid_for(M, kBnRowsPerBlock));
+    if (relu) hipLaunchKernelGGL((bn_apply_nhwc_kernel<true>), grid, dim3(kBlock), 0, st, x, affine, mean, y, (int)M, C);
+    else hipLaunchKernelGGL((bn_apply_nhwc_kernel<false>), grid, dim3(kBlock), 0, st, x, affine, mean, y, (int)M, C);
     return launch_status();
 }

@@ -99,7 +99,8 @@ def _batch_norm(bn, x, relu=False, groups=1, residual=None):
     (``_BN_IMPL = "hip"``, default; one kernel family per layout, csrc/batchnorm.hip).
     MIOpen's spatial BN runs ~10x below the HBM rate at these shapes (8-64 channels, up to 1.8 M pixels per plane:
     42 ms of a 128 ms training step); ATen's native kernels measured slower still (142 vs 128 ms per step).
-    Eval mode (a per-channel affine) and every other case go through ``F.batch_norm`` (MIOpen on ROCm)."""
+    Eval mode without autograd (inference): one HIP pass, ``mvster_bn_eval_fwd`` (affine with the running statistics, ReLU and
+    the skip connection fused).  Every other case goes through ``F.batch_norm`` (MIOpen on ROCm)."""
     training = bn.training or not bn.track_running_stats
     if groups > 1 and training:
         if x.shape[0] % groups:
@@ -120,6 +121,25 @@ def _batch_norm(bn, x, relu=False, groups=1, residual=None):
         if residual is not None and (not x.is_contiguous() or not residual.is_contiguous() or residual.shape != x.shape):
             return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu, groups) + residual
         return _BNReLUTrain.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, relu, groups, residual)
+    if (_BN_IMPL == "hip" and not training and x.is_cuda and x.dtype == torch.float32 and (x.is_contiguous() or dense_cl)
+            and x.dim() >= 3 and not (torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad)))):
+        # inference: a per-channel affine with the running statistics (+ReLU, + the skip connection) in ONE streaming pass
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        y = torch.empty_like(x)
+        scratch = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+        opt = lambda t: t.data_ptr() if t is not None else None
+        fuse_res = residual is not None and x.is_contiguous() and residual.is_contiguous() and residual.shape == x.shape
+        with _on(x.device):
+            if x.is_contiguous():
+                _lib.call("mvster_bn_eval_fwd", x.data_ptr(), opt(bn.weight), opt(bn.bias), bn.running_mean.data_ptr(),
+                          bn.running_var.data_ptr(), residual.data_ptr() if fuse_res else None, y.data_ptr(), scratch.data_ptr(),
+                          N, C, HW, float(bn.eps), 1 if relu else 0, _stream(x.device))
+            else:
+                _lib.call("mvster_bn_eval_fwd_nhwc", x.data_ptr(), opt(bn.weight), opt(bn.bias), bn.running_mean.data_ptr(),
+                          bn.running_var.data_ptr(), y.data_ptr(), scratch.data_ptr(), N * HW, C, float(bn.eps),
+                          1 if relu else 0, _stream(x.device))
+        return y if (residual is None or fuse_res) else y + residual
     if x.is_cuda and _BN_IMPL == "native":
         y = torch.native_batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps)[0]
     else:

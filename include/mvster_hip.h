@@ -295,6 +295,18 @@ int mvster_bn_train_bwd_nhwc(const float *dy, const float *x, const float *affin
                              const float *save_invstd, float *dx, float *dgamma, float *dbeta, double *sums,
                              long long M, int C, int relu, mvster_stream_t stream);
 
+/* Inference mode (model.eval(): the whole of test_mvs4.py:393-411): the statistics are the module's running ones,
+ *   y = relu?((x - running_mean) / sqrt(running_var + eps) * gamma + beta) [+ residual],
+ * ONE streaming pass instead of F.batch_norm(training=False) followed by F.relu (and the skip-connection add).
+ *   scratch : 3*C floats (the per-channel affine and mean, prepared by a C-thread launch on the same stream).
+ *   residual (may be NULL) as in mvster_bn_train_fwd_grouped.  _nhwc: channels-last storage, C in {4, 8, 16, 32, 64}. */
+int mvster_bn_eval_fwd(const float *x, const float *gamma, const float *beta, const float *running_mean,
+                       const float *running_var, const float *residual, float *y, float *scratch, int N, int C, int HW,
+                       float eps, int relu, mvster_stream_t stream);
+int mvster_bn_eval_fwd_nhwc(const float *x, const float *gamma, const float *beta, const float *running_mean,
+                            const float *running_var, float *y, float *scratch, long long M, int C, float eps, int relu,
+                            mvster_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * F3  top pyramid level without its 64-channel full-resolution map.
  * replaces: `intra_feat = F.interpolate(intra_feat, x2, bilinear, align_corners=True) + self.inner3(conv0)` followed by

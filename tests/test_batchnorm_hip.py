@@ -69,6 +69,20 @@ def test_fused_bn_relu_matches_float64_batch_norm(shape, relu, mean_shift, chann
     ref.eval()
     yre = F.relu(ref(x.double())) if relu else ref(x.double())
     assert err(ye, yre) < 5e-6
+    # inference (no autograd): ONE HIP pass -- affine with the running statistics, ReLU and the skip connection fused
+    res = torch.randn(shape, generator=g)
+    xe = x.to(dev).contiguous(memory_format=torch.channels_last) if channels_last else x.to(dev)
+    calls = []
+    m._lib.call = lambda name, *a: (calls.append(name), real_call(name, *a))[1]
+    try:
+        with torch.no_grad():
+            yi = m._batch_norm(bn, xe, relu=relu)
+            yi_res = m._batch_norm(bn, xe, relu=relu, residual=res.to(dev))
+    finally:
+        m._lib.call = real_call
+    assert calls == ["mvster_bn_eval_fwd_nhwc" if channels_last else "mvster_bn_eval_fwd"] * 2
+    assert err(yi, yre) < 2e-6 and err(yi_res, yre + res.double()) < 2e-6
+    assert yi.is_contiguous(memory_format=torch.channels_last) == xe.is_contiguous(memory_format=torch.channels_last)
 
 
 @pytest.mark.parametrize("shape,groups,relu", [((6, 8, 37, 53), 3, True), ((10, 16, 20, 24), 5, True), ((4, 64, 9, 11), 4, False),

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""End-to-end training step of the drop-in MVS4net on one GPU (informational; the headline bench is bench.py):
-FPN4 x N views (MIOpen) -> 4 x [HIP hot path + reg2d (MIOpen)] -> mono head -> MVS4net_loss (HIP sinkhorn, 10 sweeps)
--> backward -> Adam.  1600x1152 (1184 is illegal for reg2d), N = 5 views, inverse depth, group correlation.
+"""End-to-end training step of the drop-in MVS4net on one GPU (informational; the headline bench is bench.py, which also
+reports this step in its `e2e` object):
+FPN4 over the N views (HIP convolutions, BatchNorm+ReLU, fused top-down merge) -> 4 x [HIP hot path + reg2d (HIP
+convolutions on the fp32 matrix cores / direct kernels)] -> mono head -> MVS4net_loss (HIP sinkhorn, 10 sweeps) ->
+backward -> Adam.  1600x1152 (1184 is illegal for reg2d), N = 5 views, inverse depth, group correlation.
 
     python tools/e2e_bench.py [--batch 1] [--steps 3] [--height 1152] [--width 1600] [--channels-last]
 """
