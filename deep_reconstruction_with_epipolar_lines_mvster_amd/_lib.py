@@ -46,6 +46,9 @@ PROTOTYPES = {
     "mvster_softmax_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvster_sinkhorn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "mvster_sinkhorn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "mvster_sinkhorn_generic_workspace": [_i, _i, _i, _i, _i, _i, _i],
+    "mvster_sinkhorn_generic_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "mvster_sinkhorn_generic_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _i, _vp],
     "mvster_bn_train_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp],
     "mvster_bn_train_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvster_bn_train_fwd_grouped": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp],
@@ -76,7 +79,7 @@ PROTOTYPES = {
 
 RESTYPES = {"mvster_cost_volume_bwd_workspace": _ll, "mvster_cost_volume_bwd_route_workspace": _ll,
             "mvster_cost_volume_bin_counts": _ll, "mvster_conv_direct_wgrad_workspace": _ll,
-            "mvster_conv_mfma_workspace": _ll}      # everything else returns the int status
+            "mvster_conv_mfma_workspace": _ll, "mvster_sinkhorn_generic_workspace": _ll}      # everything else returns the int status
 
 MVSTER_OK = 0
 LAYOUT_NCHW = 0

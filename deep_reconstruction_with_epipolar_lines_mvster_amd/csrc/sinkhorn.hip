@@ -215,6 +215,154 @@ sinkhorn_bwd_kernel(const float* __restrict__ gt, const float* __restrict__ hypo
     for (int d = 0; d < D; ++d) gattn[bdp + (size_t)d * HW] = g * glognu[d] / (a[d] + 1e-12f);
 }
 
+// ---- any D <= 64, any number of sweeps: coverage, not speed --------------------------------------------------------------
+// The specialised kernels above keep the whole transport problem of a pixel in registers (D in {4, 8, 16}, <= 16 sweeps).
+// Every other shape (stage_splits such as 5, 6, 12, 24, 48; ot_iter > 16) runs here: the same sweeps as plain loops, the
+// pixel's vectors in a caller-provided workspace laid out [slot][pixel] (consecutive lanes = consecutive pixels: every
+// access is coalesced), the backward's per-sweep history included.  Slots, NC = D (+1 continuous):
+//   log_nu [D] | log_mu [NC] | extra [D] | u_k [D], k = 0..K | v_k [NC], k = 0..K        K = sweeps kept: 0 forward, iters backward
+struct GenericSinkhorn {
+    int D, NC, continuous, iters;
+    float eps;
+    size_t stride;              // pixels in all (B * HW): distance between slots
+    __device__ __forceinline__ size_t log_nu(int r) const { return (size_t)r * stride; }
+    __device__ __forceinline__ size_t log_mu(int c) const { return (size_t)(D + c) * stride; }
+    __device__ __forceinline__ size_t extra(int r) const { return (size_t)(D + NC + r) * stride; }
+    __device__ __forceinline__ size_t u(int k, int r) const { return (size_t)(2 * D + NC + k * (D + NC) + r) * stride; }
+    __device__ __forceinline__ size_t v(int k, int c) const { return (size_t)(2 * D + NC + k * (D + NC) + D + c) * stride; }
+};
+
+__device__ __forceinline__ float generic_cost(const GenericSinkhorn& g, const float* __restrict__ w, int r, int c) {
+    return (g.continuous && c == g.D) ? w[g.extra(r)] : fabsf((float)(r - c));
+}
+
+// fills log_nu / log_mu / extra of one pixel (w already points at the pixel); false: masked out
+__device__ __forceinline__ bool generic_load(const GenericSinkhorn& g, float* __restrict__ w, const float* __restrict__ gt,
+                                             const float* __restrict__ hypo, const float* __restrict__ attn,
+                                             const uint8_t* __restrict__ mask, size_t bp, size_t bdp, int HW) {
+    if (mask[bp] == 0) return false;
+    const float gv = gt[bp];
+    int gi = 0;
+    float best = 0.0f;
+    for (int d = 0; d < g.D; ++d) {
+        w[g.log_nu(d)] = logf(attn[bdp + (size_t)d * HW] + 1e-12f);
+        const float dist = fabsf(hypo[bdp + (size_t)d * HW] - gv);
+        if (d == 0 || dist < best) { best = dist; gi = d; }
+    }
+    if (g.continuous) {
+        for (int c = 0; c < g.D; ++c) w[g.log_mu(c)] = logf(1e-12f);
+        w[g.log_mu(g.D)] = logf(1.0f + 1e-12f);
+        const float h0 = hypo[bdp], h1 = hypo[bdp + (size_t)HW], h2 = hypo[bdp + 2 * (size_t)HW];
+        const float itv = 1.0f / h2 - 1.0f / h1;
+        const float bin = (1.0f / gv - 1.0f / h0) / itv;
+        for (int r = 0; r < g.D; ++r) w[g.extra(r)] = fabsf(bin - (float)r);
+    } else {
+        for (int c = 0; c < g.D; ++c) w[g.log_mu(c)] = logf((c == gi ? 1.0f : 0.0f) + 1e-12f);
+    }
+    return true;
+}
+
+// one sweep from (u_from) to (v_to, u_to); the slots may coincide (forward: everything in sweep 0)
+__device__ __forceinline__ void generic_sweep(const GenericSinkhorn& g, float* __restrict__ w, int from, int to) {
+    for (int c = 0; c < g.NC; ++c) {
+        float mx = -INFINITY;
+        for (int r = 0; r < g.D; ++r) mx = fmaxf(mx, generic_cost(g, w, r, c) / g.eps + w[g.u(from, r)]);
+        float s = 0.0f;
+        for (int r = 0; r < g.D; ++r) s += expf(generic_cost(g, w, r, c) / g.eps + w[g.u(from, r)] - mx);
+        w[g.v(to, c)] = w[g.log_mu(c)] - (mx + logf(s));
+    }
+    for (int r = 0; r < g.D; ++r) {
+        float mx = -INFINITY;
+        for (int c = 0; c < g.NC; ++c) mx = fmaxf(mx, generic_cost(g, w, r, c) / g.eps + w[g.v(to, c)]);
+        float s = 0.0f;
+        for (int c = 0; c < g.NC; ++c) s += expf(generic_cost(g, w, r, c) / g.eps + w[g.v(to, c)] - mx);
+        const float unew = w[g.log_nu(r)] - (mx + logf(s));
+        w[g.u(to, r)] = unew;       // from == to: row r of u is not read again in this sweep (its LSE is over v only)
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+sinkhorn_generic_fwd_kernel(const float* __restrict__ gt, const float* __restrict__ hypo, const float* __restrict__ attn,
+                            const uint8_t* __restrict__ mask, float* __restrict__ pix_loss, float* __restrict__ tmap,
+                            float* __restrict__ workspace, int HW, GenericSinkhorn g) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= HW) return;
+    const size_t bp = (size_t)b * HW + p, bdp = (size_t)b * g.D * HW + p;
+    float* __restrict__ w = workspace + bp;
+    float* __restrict__ tm = tmap != nullptr ? tmap + bp * (size_t)(g.D * g.NC) : nullptr;
+    if (!generic_load(g, w, gt, hypo, attn, mask, bp, bdp, HW)) {
+        pix_loss[bp] = 0.0f;
+        if (tm != nullptr)
+            for (int i = 0; i < g.D * g.NC; ++i) tm[i] = __builtin_nanf("");
+        return;
+    }
+    for (int r = 0; r < g.D; ++r) w[g.u(0, r)] = 0.0f;
+    for (int c = 0; c < g.NC; ++c) w[g.v(0, c)] = 0.0f;
+    for (int it = 0; it < g.iters; ++it) generic_sweep(g, w, 0, 0);
+    float loss = 0.0f;
+    for (int r = 0; r < g.D; ++r)
+        for (int c = 0; c < g.NC; ++c) {
+            const float cost = generic_cost(g, w, r, c);
+            const float T = expf(cost / g.eps + w[g.u(0, r)] + w[g.v(0, c)]);
+            loss += T * cost;
+            if (tm != nullptr) tm[r * g.NC + c] = T;
+        }
+    pix_loss[bp] = loss;
+}
+
+// reverse sweep as in sinkhorn_bwd_kernel, the history u_k, v_k read back from the workspace; ubar / vbar / g_lognu reuse the
+// slots of sweep 0's v (vbar), and two scratch rows appended behind the history (ubar, g_lognu)
+__global__ void __launch_bounds__(kBlock)
+sinkhorn_generic_bwd_kernel(const float* __restrict__ gt, const float* __restrict__ hypo, const float* __restrict__ attn,
+                            const uint8_t* __restrict__ mask, const float* __restrict__ gpix, float* __restrict__ gattn,
+                            float* __restrict__ workspace, int HW, GenericSinkhorn g) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= HW) return;
+    const size_t bp = (size_t)b * HW + p, bdp = (size_t)b * g.D * HW + p;
+    float* __restrict__ w = workspace + bp;
+    if (!generic_load(g, w, gt, hypo, attn, mask, bp, bdp, HW)) {
+        for (int d = 0; d < g.D; ++d) gattn[bdp + (size_t)d * HW] = 0.0f;
+        return;
+    }
+    const int K = g.iters;
+    for (int r = 0; r < g.D; ++r) w[g.u(0, r)] = 0.0f;
+    for (int k = 1; k <= K; ++k) generic_sweep(g, w, k - 1, k);
+    // three more rows behind the history: ubar [D], glognu [D], vbar [NC]
+    const size_t ubar0 = g.u(K + 1, 0), gln0 = ubar0 + (size_t)g.D * g.stride, vbar0 = gln0 + (size_t)g.D * g.stride;
+    for (int r = 0; r < g.D; ++r) { w[ubar0 + r * g.stride] = 0.0f; w[gln0 + r * g.stride] = 0.0f; }
+    for (int c = 0; c < g.NC; ++c) w[vbar0 + c * g.stride] = 0.0f;
+    for (int r = 0; r < g.D; ++r)
+        for (int c = 0; c < g.NC; ++c) {
+            const float cost = generic_cost(g, w, r, c);
+            const float uK = K > 0 ? w[g.u(K, r)] : 0.0f, vK = K > 0 ? w[g.v(K, c)] : 0.0f;
+            const float wt = expf(cost / g.eps + uK + vK) * cost;
+            w[ubar0 + r * g.stride] += wt;
+            w[vbar0 + c * g.stride] += wt;
+        }
+    for (int k = K; k >= 1; --k) {
+        for (int r = 0; r < g.D; ++r) w[gln0 + r * g.stride] += w[ubar0 + r * g.stride];
+        for (int c = 0; c < g.NC; ++c) {
+            float acc = 0.0f;
+            for (int r = 0; r < g.D; ++r)
+                acc = fmaf(w[ubar0 + r * g.stride], expf(generic_cost(g, w, r, c) / g.eps + w[g.v(k, c)] + w[g.u(k, r)] - w[g.log_nu(r)]), acc);
+            w[vbar0 + c * g.stride] -= acc;
+        }
+        for (int r = 0; r < g.D; ++r) {
+            float acc = 0.0f;
+            for (int c = 0; c < g.NC; ++c)
+                acc = fmaf(w[vbar0 + c * g.stride], expf(generic_cost(g, w, r, c) / g.eps + w[g.u(k - 1, r)] + w[g.v(k, c)] - w[g.log_mu(c)]), acc);
+            w[ubar0 + r * g.stride] = -acc;
+        }
+        for (int c = 0; c < g.NC; ++c) w[vbar0 + c * g.stride] = 0.0f;
+    }
+    const float gp = gpix[bp];
+    for (int d = 0; d < g.D; ++d) gattn[bdp + (size_t)d * HW] = gp * w[gln0 + d * g.stride] / (attn[bdp + (size_t)d * HW] + 1e-12f);
+}
+
+constexpr int kGenericSinkhornMaxD = 64;
+
 static int check_sinkhorn(const void* a, const void* b, const void* c, const void* d, const void* e, int B, int D, int H,
                           int W, int iters, float eps, int continuous) {
     MVSTER_REQUIRE_PTR(a); MVSTER_REQUIRE_PTR(b); MVSTER_REQUIRE_PTR(c); MVSTER_REQUIRE_PTR(d); MVSTER_REQUIRE_PTR(e);
@@ -261,5 +409,50 @@ extern "C" int mvster_sinkhorn_bwd(const float* gt_depth, const float* hypo, con
     dim3 grid(grid_for(HW, kBlock), B);
     const hipStream_t st = as_stream(stream);
     MVSTER_SINKHORN_DISPATCH(sinkhorn_bwd_kernel, gt_depth, hypo, attn, mask, gpix, gattn, HW, iters, eps);
+    return launch_status();
+}
+
+// Generic route: any D <= 64 (continuous: D >= 3), any iters >= 0.  workspace: mvster_sinkhorn_generic_workspace() floats.
+extern "C" long long mvster_sinkhorn_generic_workspace(int B, int D, int H, int W, int iters, int continuous, int backward) {
+    if (B <= 0 || D <= 0 || D > mvster::kGenericSinkhornMaxD || H <= 0 || W <= 0 || iters < 0) return -1;
+    const long long NC = D + (continuous ? 1 : 0), px = (long long)B * H * W;
+    const long long sweeps = backward ? iters + 1 : 1;
+    return px * (2 * D + NC + sweeps * (D + NC) + (backward ? 2 * D + NC : 0));
+}
+
+static int check_generic(const void* a, const void* b, const void* c, const void* d, const void* e, const void* ws, long long have,
+                         int B, int D, int H, int W, int iters, float eps, int continuous, int backward) {
+    MVSTER_REQUIRE_PTR(a); MVSTER_REQUIRE_PTR(b); MVSTER_REQUIRE_PTR(c); MVSTER_REQUIRE_PTR(d); MVSTER_REQUIRE_PTR(e); MVSTER_REQUIRE_PTR(ws);
+    MVSTER_REQUIRE_SHAPE(B > 0 && B <= 65535 && D > 0 && H > 0 && W > 0 && (long long)H * W <= mvster::kMaxPlane);
+    MVSTER_REQUIRE_SHAPE(iters >= 0 && eps != 0.0f && (!continuous || D >= 3));
+    if (D > mvster::kGenericSinkhornMaxD) return MVSTER_ERR_UNSUPPORTED;
+    MVSTER_REQUIRE_SHAPE(have >= mvster_sinkhorn_generic_workspace(B, D, H, W, iters, continuous, backward));
+    return MVSTER_OK;
+}
+
+extern "C" int mvster_sinkhorn_generic_fwd(const float* gt_depth, const float* hypo, const float* attn, const uint8_t* mask,
+                                           float* pix_loss, float* tmap, float* workspace, long long workspace_floats, int B, int D,
+                                           int H, int W, int iters, float eps, int continuous, mvster_stream_t stream) {
+    using namespace mvster;
+    if (int rc = check_generic(gt_depth, hypo, attn, mask, pix_loss, workspace, workspace_floats, B, D, H, W, iters, eps, continuous, 0))
+        return rc;
+    const int HW = H * W;
+    GenericSinkhorn g{D, D + (continuous ? 1 : 0), continuous ? 1 : 0, iters, eps, (size_t)B * HW};
+    hipLaunchKernelGGL(sinkhorn_generic_fwd_kernel, dim3(grid_for(HW, kBlock), B), dim3(kBlock), 0, as_stream(stream), gt_depth, hypo,
+                       attn, mask, pix_loss, tmap, workspace, HW, g);
+    return launch_status();
+}
+
+extern "C" int mvster_sinkhorn_generic_bwd(const float* gt_depth, const float* hypo, const float* attn, const uint8_t* mask,
+                                           const float* gpix, float* gattn, float* workspace, long long workspace_floats, int B,
+                                           int D, int H, int W, int iters, float eps, int continuous, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(gpix);
+    if (int rc = check_generic(gt_depth, hypo, attn, mask, gattn, workspace, workspace_floats, B, D, H, W, iters, eps, continuous, 1))
+        return rc;
+    const int HW = H * W;
+    GenericSinkhorn g{D, D + (continuous ? 1 : 0), continuous ? 1 : 0, iters, eps, (size_t)B * HW};
+    hipLaunchKernelGGL(sinkhorn_generic_bwd_kernel, dim3(grid_for(HW, kBlock), B), dim3(kBlock), 0, as_stream(stream), gt_depth, hypo,
+                       attn, mask, gpix, gattn, workspace, HW, g);
     return launch_status();
 }

@@ -54,32 +54,48 @@ class _SinkhornPixelLoss(torch.autograd.Function):
         return gattn, None, None, None, None, None, None, None
 
 
-def _sinkhorn_device_ops(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous):
-    """Shapes the fused kernel does not instantiate (D not in 4/8/16, iters > 16): the same log-domain sweeps as
-    device tensor ops (still no CPU path)."""
-    B, D, H, W = attn_weight.shape
-    dev = attn_weight.device
-    idx = torch.arange(D, device=dev, dtype=torch.float32)
-    cost = (idx[:, None] - idx[None, :]).abs().expand(B, H * W, D, D)
-    if continuous:
-        step = 1 / hypo_depth[:, 2] - 1 / hypo_depth[:, 1]
-        gbin = ((1 / gt_depth - 1 / hypo_depth[:, 0]) / step).masked_fill(~mask, 10.0)
-        last = (gbin.reshape(B, H * W, 1) - idx.view(1, 1, D)).abs()
-        cost = torch.cat([cost, last.unsqueeze(3)], 3)
-        mu = torch.zeros(B, H * W, D + 1, device=dev)
-        mu[:, :, -1] = 1
-    else:
-        gi = (hypo_depth - gt_depth[:, None]).abs().min(1)[1].reshape(B, H * W, 1)
-        mu = torch.zeros(B, H * W, D, device=dev).scatter_(2, gi, 1.0)
-    nu = attn_weight.permute(0, 2, 3, 1).reshape(B, H * W, D)
-    log_mu, log_nu = (mu + 1e-12).log(), (nu + 1e-12).log()
-    u, v = torch.zeros_like(log_nu), torch.zeros_like(log_mu)
-    for _ in range(iters):
-        v = log_mu - torch.logsumexp(cost / eps + u.unsqueeze(3), dim=2)
-        u = log_nu - torch.logsumexp(cost / eps + v.unsqueeze(2), dim=3)
-    tmap = (cost / eps + u.unsqueeze(3) + v.unsqueeze(2)).exp()
-    pix = (tmap * cost).sum((2, 3)).reshape(B, H, W) * mask
-    return pix, tmap
+class _SinkhornPixelLossGeneric(torch.autograd.Function):
+    """Shapes the register-resident kernels do not instantiate (D not in 4/8/16 up to 64, more than 16 sweeps): the generic
+    HIP kernels of csrc/sinkhorn.hip (plain loops, vectors and per-sweep history in a workspace from torch's allocator)."""
+
+    @staticmethod
+    def forward(ctx, attn, gt, hypo, mask_u8, iters, eps, continuous, want_tmap):
+        B, D, H, W = attn.shape
+        dev = attn.device
+        pix = torch.empty(B, H, W, dtype=torch.float32, device=dev)
+        tmap = torch.empty(B, H * W, D, D + (1 if continuous else 0), dtype=torch.float32, device=dev) if want_tmap else None
+        need = _lib.load().mvster_sinkhorn_generic_workspace(B, D, H, W, int(iters), 1 if continuous else 0, 0)
+        ws = torch.empty(need, dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.call("mvster_sinkhorn_generic_fwd", gt.data_ptr(), hypo.data_ptr(), attn.data_ptr(), mask_u8.data_ptr(),
+                      pix.data_ptr(), tmap.data_ptr() if want_tmap else None, ws.data_ptr(), need, B, D, H, W, int(iters),
+                      float(eps), 1 if continuous else 0, _stream(dev))
+        ctx.save_for_backward(attn, gt, hypo, mask_u8)
+        ctx.cfg = (int(iters), float(eps), bool(continuous))
+        if want_tmap:
+            ctx.mark_non_differentiable(tmap)
+            return pix, tmap
+        return pix, attn.new_empty(0)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gpix, _gtmap):
+        attn, gt, hypo, mask_u8 = ctx.saved_tensors
+        iters, eps, continuous = ctx.cfg
+        B, D, H, W = attn.shape
+        dev = attn.device
+        gpix = gpix.contiguous()
+        gattn = torch.empty_like(attn)
+        need = _lib.load().mvster_sinkhorn_generic_workspace(B, D, H, W, iters, 1 if continuous else 0, 1)
+        ws = torch.empty(need, dtype=torch.float32, device=dev)
+        with _on(dev):
+            _lib.call("mvster_sinkhorn_generic_bwd", gt.data_ptr(), hypo.data_ptr(), attn.data_ptr(), mask_u8.data_ptr(),
+                      gpix.data_ptr(), gattn.data_ptr(), ws.data_ptr(), need, B, D, H, W, iters, eps, 1 if continuous else 0,
+                      _stream(dev))
+        return gattn, None, None, None, None, None, None, None
+
+
+_GENERIC_MAX_D = 64
 
 
 def _pixel_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous, want_tmap):
@@ -91,12 +107,19 @@ def _pixel_loss(gt_depth, hypo_depth, attn_weight, mask, iters, eps, continuous,
     B, D, H, W = attn.shape
     if hypo.shape != attn.shape or tuple(gt.shape) != (B, H, W) or tuple(mask.shape) != (B, H, W):
         raise RuntimeError("sinkhorn: gt_depth/mask must be [B,H,W] and hypo_depth/attn_weight [B,D,H,W]")
-    if D in _FUSED_D and 0 <= int(iters) <= _MAX_ITERS and (not continuous or D >= 3):
-        mask_u8 = mask.contiguous().view(torch.uint8)
-        pix, tmap = _SinkhornPixelLoss.apply(attn, gt, hypo, mask_u8, int(iters), float(eps), bool(continuous),
-                                             bool(want_tmap))
-        return pix, (tmap if want_tmap else None)
-    return _sinkhorn_device_ops(gt, hypo, attn, mask, int(iters), eps, continuous)
+    if continuous and D < 3:
+        raise IndexError("continuous bins need at least 3 hypotheses (reads hypo_depth[:,2], models/mvs4net_utils.py:1183)")
+    if int(iters) < 0:
+        raise ValueError("iters must be >= 0")
+    mask_u8 = mask.contiguous().view(torch.uint8)
+    if D in _FUSED_D and int(iters) <= _MAX_ITERS:
+        fn = _SinkhornPixelLoss
+    elif D <= _GENERIC_MAX_D:
+        fn = _SinkhornPixelLossGeneric
+    else:
+        raise RuntimeError("sinkhorn: at most %d depth hypotheses (got %d)" % (_GENERIC_MAX_D, D))
+    pix, tmap = fn.apply(attn, gt, hypo, mask_u8, int(iters), float(eps), bool(continuous), bool(want_tmap))
+    return pix, (tmap if want_tmap else None)
 
 
 def sinkhorn(gt_depth, hypo_depth, attn_weight, mask, iters, eps=1, continuous=False):

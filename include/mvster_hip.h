@@ -251,6 +251,18 @@ int mvster_sinkhorn_bwd(const float *gt_depth, const float *hypo, const float *a
                         const float *gpix, float *gattn, int B, int D, int H, int W, int iters, float eps,
                         int continuous, mvster_stream_t stream);
 
+/* The same loss for the shapes the register-resident kernels do not instantiate: any D <= 64 (stage_splits such as 5, 6, 12,
+ * 24, 48), any number of sweeps -- plain loops, the pixel's vectors and (backward) its per-sweep history in a workspace
+ * laid out [slot][pixel]; coverage, not speed.  D > 64 -> MVSTER_ERR_UNSUPPORTED.
+ *   workspace: mvster_sinkhorn_generic_workspace(B, D, H, W, iters, continuous, backward) floats (-1: unsupported). */
+long long mvster_sinkhorn_generic_workspace(int B, int D, int H, int W, int iters, int continuous, int backward);
+int mvster_sinkhorn_generic_fwd(const float *gt_depth, const float *hypo, const float *attn, const uint8_t *mask,
+                                float *pix_loss, float *tmap, float *workspace, long long workspace_floats, int B, int D,
+                                int H, int W, int iters, float eps, int continuous, mvster_stream_t stream);
+int mvster_sinkhorn_generic_bwd(const float *gt_depth, const float *hypo, const float *attn, const uint8_t *mask,
+                                const float *gpix, float *gattn, float *workspace, long long workspace_floats, int B, int D,
+                                int H, int W, int iters, float eps, int continuous, mvster_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * F2/F3  training-mode BatchNorm (+ optional fused ReLU) over [N,C,HW] planes (NCHW, or [B*D,C,H,W] depth slices).
  * replaces: the BatchNorm2d/3d + ReLU after every convolution of FPN4 / reg2d / the mono head
