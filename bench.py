@@ -408,14 +408,22 @@ def free_port():
 def launch_ranks(n, argv, timeout_s=1500.0, program=None):
     """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters, so none inherits GPU
     state -- this parent has made no HIP call), wait for all of them, relay rank 0's JSON line.  Any rank failing
-    terminates the others and makes the parent exit non-zero.  Returns the exit code."""
+    terminates the others and makes the parent exit non-zero; the output of every rank > 0 is kept in a temporary file
+    and replayed on stderr, prefixed by its rank, when anything failed (a traceback on rank 3 is not lost).
+    Returns the exit code."""
+    import tempfile
     port = free_port()
-    procs = []
+    procs, logs = [], []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: RCCL exchanges device-memory handles between the ranks' processes; the hosts this
+        # runs on support only the dmabuf IPC path, and with the legacy mode the first collective fails with
+        # "hipIpcGetMemHandle: invalid argument".  Inherited if already set; forced here so a bare shell works too.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        log = None if r == 0 else tempfile.TemporaryFile(mode="w+b")
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, program or os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else log, stderr=None if r == 0 else subprocess.STDOUT))
     deadline = time.time() + timeout_s
     rc = 0
     pending = set(range(n))
@@ -448,6 +456,15 @@ def launch_ranks(n, argv, timeout_s=1500.0, program=None):
                 pr.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 pr.kill()
+        for r, log in enumerate(logs):
+            if log is None:
+                continue
+            if rc != 0:
+                log.seek(0)
+                for line in log.read().decode(errors="replace").splitlines()[-60:]:
+                    print("[rank %d] %s" % (r, line), file=sys.stderr)
+            log.close()
+        sys.stderr.flush()
     sys.stdout.write(out0.decode(errors="replace"))
     sys.stdout.flush()
     return rc

@@ -866,7 +866,9 @@ extern "C" long long mvster_conv_mfma_workspace(int N, int Cin, int Cout, int H,
         const WgPlan pl = wgrad_plan(N, Cin, Cout, Ho, Wo, K, stride);
         return (long long)pl.groups * pl.grid_x * pl.E;
     }
-    const int cb = stride == 1 ? MVSTER_MF_CB_S1 : 4;
+    // packed weights [CinPad][K*K][CoutPad]: the forward kernels stage 8 (stride 1) / 4 (stride 2) input channels per step,
+    // the transposed kernel 8 (K = 3) / 4 (K = 5)
+    const int cb = op == MVSTER_CONV_OP_TRANSPOSED ? (K == 3 ? 8 : 4) : (stride == 1 ? MVSTER_MF_CB_S1 : 4);
     return (long long)((Cin + cb - 1) / cb * cb) * K * K * ((Cout + 31) / 32 * 32);
 }
 

@@ -150,9 +150,10 @@ def _range_miss(hypo_depth, depth_gt, inverse):
 
 def _masked_mean(values, mask):
     """``values[mask].mean()`` without the boolean gather: no data-dependent shape, hence no host synchronisation (the
-    step stays capturable in a HIP graph); an empty mask gives NaN either way."""
-    m = mask.to(values.dtype)
-    return (values * m).sum() / m.sum()
+    step stays capturable in a HIP graph); an empty mask gives NaN either way.  Entries outside the mask are dropped, not
+    multiplied by zero: a NaN / Inf there (invalid ground truth, an overflowed prediction) neither poisons the mean nor gets
+    a gradient -- exactly like the reference's indexing."""
+    return torch.where(mask, values, values.new_zeros(())).sum() / mask.sum()
 
 
 def _stage_items(inputs):

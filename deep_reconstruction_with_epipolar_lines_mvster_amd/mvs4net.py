@@ -285,7 +285,7 @@ class _DirectConv2d(torch.autograd.Function):
                 elif dgrad == "mfma":                      # stride 2: dy scattered back = a transposed convolution, as a gather
                     dx = torch.empty_like(x)
                     Hd, Wd = dy.shape[2], dy.shape[3]
-                    ws, need = _mfma_workspace(lib, dev, N, Cout, Cin, Hd, Wd, K, 2, 0)
+                    ws, need = _mfma_workspace(lib, dev, N, Cout, Cin, Hd, Wd, K, 2, 2)
                     _lib.call("mvster_conv_mfma_transposed", dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), ws.data_ptr(), need,
                               N, Cout, Cin, Hd, Wd, H, W, K, _stream(dev))
                 else:
@@ -366,7 +366,7 @@ class _MfmaConvTranspose2d(torch.autograd.Function):
         Cout, K = weight.shape[1], weight.shape[2]
         dev = x.device
         y = torch.empty(N, Cout, 2 * H, 2 * W, dtype=torch.float32, device=dev)
-        ws, need = _mfma_workspace(_lib.load(), dev, N, Cin, Cout, H, W, K, 2, 0)
+        ws, need = _mfma_workspace(_lib.load(), dev, N, Cin, Cout, H, W, K, 2, 2)
         with _on(dev):
             _lib.call("mvster_conv_mfma_transposed", x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), need,
                       N, Cin, Cout, H, W, 2 * H, 2 * W, K, _stream(dev))
@@ -423,7 +423,10 @@ _DIRECT_MAX_COUT = 16                # forward: few output channels ...
 _DIRECT_MAX_PRODUCT = 1024           # ... and Cin * Cout up to 64 x 16 (two pixels per lane from 16 accumulators up)
 _DIRECT_MAX_DGRAD_CIN = 16           # input gradient: Cin accumulators per lane (more when the layer has <= 8 output channels)
 _DIRECT_MAX_WGRAD_PRODUCT = 128      # weight gradient: Cout <= 8, or Cin * Cout up to this
-_MFMA_MAX_WGRAD_CIN = 96             # weight gradient: beyond, the (co, ci) block groups re-read the tiles too often
+_DIRECT_WGRAD_COUT = (1, 8, 16)      # output channel counts mvster_conv_direct_wgrad instantiates (csrc/conv_direct.hip)
+_MFMA_MAX_WGRAD_CIN = 192            # weight gradient on the matrix cores up to reg2d's conv6 (3 x 64 virtual input channels): slower
+#                                    # than MIOpen there (0.82 vs 0.39 ms) but the model then runs without a single MIOpen
+#                                    # kernel, so the reference drivers' cudnn.benchmark = True triggers no MIOpen find
 
 
 def _conv_route(Cin, Cout, K, stride):
@@ -441,7 +444,7 @@ def _conv_route(Cin, Cout, K, stride):
         dgrad = "mfma" if mfma_ok and (stride == 1 or K in (3, 5)) else "miopen"
     if _MFMA_CONV and K == 3 and stride == 1 and Cout in (4, 8) and Cin >= 3:
         wgrad = "mfma"                 # <= 8 output channels: the tap rows packed next to them on the MFMA's column axis
-    elif direct_ok and (Cout <= 8 or Cin * Cout <= _DIRECT_MAX_WGRAD_PRODUCT):
+    elif direct_ok and Cout in _DIRECT_WGRAD_COUT and (Cout <= 8 or Cin * Cout <= _DIRECT_MAX_WGRAD_PRODUCT):
         wgrad = "direct"
     else:
         wgrad = "mfma" if mfma_ok and Cin <= _MFMA_MAX_WGRAD_CIN else "miopen"

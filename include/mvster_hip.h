@@ -346,6 +346,7 @@ int mvster_fpn_head_gather_bwd(const float *dy, float *dg, int N, int h, int w, 
  *   Unsupported (K, stride) -> MVSTER_ERR_UNSUPPORTED; mvster_conv_mfma_supported() says so beforehand. */
 #define MVSTER_CONV_OP_FWD 0
 #define MVSTER_CONV_OP_WGRAD 1
+#define MVSTER_CONV_OP_TRANSPOSED 2     /* mvster_conv_mfma_transposed (pass stride = 2): its packing differs from the forward's */
 int mvster_conv_mfma_supported(int Cin, int Cout, int K, int stride);
 long long mvster_conv_mfma_workspace(int N, int Cin, int Cout, int H, int W, int K, int stride, int op);
 int mvster_conv_mfma_fwd(const float *x, const float *weight, const float *bias, float *y, float *workspace,

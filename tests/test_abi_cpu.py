@@ -191,7 +191,7 @@ def test_convolution_routing_policy_is_pure_host_logic():
     r = mvs4net._conv_route
     assert r(3, 8, 3, 1) == ("direct", "direct", "mfma") and r(8, 1, 1, 1) == ("direct", "direct", "direct")
     assert r(64, 64, 3, 1) == ("mfma", "mfma", "mfma") and r(16, 32, 5, 2) == ("mfma", "mfma", "mfma")
-    assert r(192, 64, 3, 1) == ("mfma", "mfma", "miopen") and r(8, 8, 5, 1) is None
+    assert r(192, 64, 3, 1) == ("mfma", "mfma", "mfma") and r(8, 8, 5, 1) is None       # no MIOpen operation left in the model
     try:
         mvs4net._MFMA_CONV = False
         assert r(64, 64, 3, 1) is None and r(8, 8, 3, 1) == ("direct", "direct", "direct")
@@ -199,3 +199,39 @@ def test_convolution_routing_policy_is_pure_host_logic():
         assert r(8, 8, 3, 1) is None
     finally:
         mvs4net._MFMA_CONV = mvs4net._DIRECT_CONV = True
+
+
+def test_conv_routes_are_accepted_by_the_kernels_they_name(lib):
+    """mvs4net._conv_route (pure host logic) never hands an operation to a HIP kernel family that would refuse it: every
+    (forward, input gradient, weight gradient) route for Cout in (1, 3, 4, 8, 16) x K in (1, 3) x both _MFMA_CONV settings is
+    checked against the matching *_supported query / the instantiated output-channel counts of the direct weight gradient."""
+    from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net as m
+    saved = m._MFMA_CONV
+    try:
+        for mfma in (True, False):
+            m._MFMA_CONV = mfma
+            for Cout in (1, 3, 4, 8, 16, 32):
+                for Cin in (1, 2, 3, 4, 8, 16, 48, 64, 192):
+                    for K in (1, 3):
+                        for stride in (1, 2):
+                            route = m._conv_route(Cin, Cout, K, stride)
+                            if route is None:
+                                continue
+                            fwd, dgrad, wgrad = route
+                            if fwd == "direct":
+                                assert stride == 1 and lib.mvster_conv_direct_supported(Cin, Cout, K), (Cin, Cout, K, stride)
+                            if fwd == "mfma":
+                                assert lib.mvster_conv_mfma_supported(Cin, Cout, K, stride)
+                            if dgrad == "direct":
+                                assert stride == 1 and lib.mvster_conv_direct_supported(Cout, Cin, K)
+                            if dgrad == "mfma":
+                                assert lib.mvster_conv_mfma_supported(Cout, Cin, K, stride)
+                            if wgrad == "direct":
+                                assert stride == 1 and Cout in m._DIRECT_WGRAD_COUT, (Cin, Cout, K, mfma)
+                            if wgrad == "mfma":
+                                assert lib.mvster_conv_mfma_supported(Cin, Cout, K, stride) or (K == 3 and stride == 1 and Cout in (4, 8))
+    finally:
+        m._MFMA_CONV = saved
+    # the transposed kernel's workspace is queried with its own op code: 8-channel packing for K = 3
+    q = lib.mvster_conv_mfma_workspace
+    assert q(1, 20, 36, 14, 22, 3, 2, 2) == 24 * 9 * 64 and q(1, 20, 36, 14, 22, 3, 2, 0) == 20 * 9 * 64

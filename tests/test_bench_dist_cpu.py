@@ -81,6 +81,7 @@ import torch.distributed as dist
 dist.init_process_group(backend="gloo", init_method="env://")
 rank, world = dist.get_rank(), dist.get_world_size()
 if "--fail-on-rank-1" in sys.argv and rank == 1:
+    print("rank 1 is about to fail", flush=True)
     sys.exit(3)
 t = torch.tensor([float(rank + 1)])
 dist.all_reduce(t)
@@ -107,7 +108,7 @@ def test_self_launcher_starts_ranks_and_relays_rank0(tmp_path, capsys):
     assert d == {"world": 2, "sum": 3.0, "local_rank": "0", "argv": ["--gpus", "2", "--steps", "1"]}
 
 
-def test_self_launcher_propagates_a_failing_rank(tmp_path):
+def test_self_launcher_propagates_a_failing_rank(tmp_path, capsys):
     import bench
     prog = tmp_path / "rank_program.py"
     prog.write_text(RANK_PROGRAM)
@@ -115,6 +116,8 @@ def test_self_launcher_propagates_a_failing_rank(tmp_path):
     rc = bench.launch_ranks(2, ["--fail-on-rank-1"], timeout_s=120, program=str(prog))
     assert rc != 0                       # rank 1 died: the surviving rank is terminated, the parent reports failure
     assert time.time() - t0 < 100
+    err = capsys.readouterr().err        # ... and what rank 1 printed before it died is replayed, prefixed by its rank
+    assert "rank 1 exited" in err and "[rank 1]" in err
 
 
 def test_exchange_buckets_add_up_to_the_reference_parameter_count():

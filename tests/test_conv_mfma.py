@@ -27,6 +27,9 @@ CASES = [  # N, Cin, Cout, H, W, K, stride, bias
     (2, 8, 16, 32, 48, 3, 2, False), (1, 16, 32, 35, 67, 3, 2, False),
     (1, 32, 64, 24, 40, 3, 2, False), (2, 8, 16, 40, 64, 5, 2, False), (1, 16, 32, 33, 61, 5, 2, False),
     (1, 32, 64, 20, 36, 5, 2, True), (5, 32, 32, 16, 32, 3, 1, False),
+    # stride-2 layers whose GEMM-K channel count is 4 mod 8: the transposed (input-gradient) kernel packs its weights in
+    # blocks of 8 input channels, the forward in blocks of 4 -- their workspace queries differ (MVSTER_CONV_OP_TRANSPOSED)
+    (1, 12, 20, 18, 30, 3, 2, False), (2, 20, 36, 14, 22, 3, 2, False),
     # <= 8 output channels, 3x3 stride 1: the weight gradient with the tap rows packed next to the output channels
     (2, 64, 8, 37, 53, 3, 1, False), (1, 8, 8, 30, 70, 3, 1, True), (4, 4, 8, 13, 33, 3, 1, False), (1, 3, 8, 6, 40, 3, 1, False),
     (2, 16, 4, 19, 31, 3, 1, False), (1, 40, 5, 12, 64, 3, 1, False),

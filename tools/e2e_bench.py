@@ -36,8 +36,13 @@ def main():
                          "step without the ~1600 kernel launches' host-side cost")
     ap.add_argument("--ddp", action="store_true",
                     help="wrap the model in DistributedDataParallel over RCCL like train_mvs4.py:562-570 (one process per GPU; "
-                         "start with torch.distributed.run, or alone for a one-rank group)")
+                         "start with torch.distributed.run, with --gpus N, or alone for a one-rank group)")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="with --ddp and no launcher: start this many ranks (one per GPU) through bench.launch_ranks")
     args = ap.parse_args()
+    if args.ddp and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one (nothing above has touched the GPU); rank 0's output is relayed, a failing rank's is shown
+        raise SystemExit(bench.launch_ranks(args.gpus, sys.argv[1:], program=os.path.abspath(__file__)))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -113,8 +118,11 @@ def main():
         import torch.distributed as dist
         print("DDP over %s, %d rank(s)" % (dist.get_backend(), dist.get_world_size()), flush=True)
         dist.destroy_process_group()
-    print("e2e %s step%s (bn=%s): %dx%d, N=%d, B=%d, channels_last=%s: %.1f ms/step = %.2f ref-views/s, peak mem %.1f GB"
-          % ("eval" if args.eval else "train", " as one HIP graph" if args.graph else "", args.bn, W, H, N, B, args.channels_last, dt * 1e3, B / dt,
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1")) if args.ddp else 1
+    print("e2e %s step%s (bn=%s): %dx%d, N=%d, B=%d per rank x %d rank(s), channels_last=%s: %.1f ms/step = %.2f ref-views/s, peak mem %.1f GB"
+          % ("eval" if args.eval else "train", " as one HIP graph" if args.graph else "", args.bn, W, H, N, B, world, args.channels_last, dt * 1e3, world * B / dt,
              torch.cuda.max_memory_allocated() / 1e9), flush=True)
 
 
