@@ -63,7 +63,7 @@ def test_routing_policy():
     assert route(32, 32, 3, 1) == ("mfma", "mfma", "mfma")
     assert route(8, 16, 3, 2) == ("mfma", "mfma", "mfma")                   # stride 2: input gradient = the transposed kernel
     assert route(32, 64, 5, 2) == ("mfma", "mfma", "mfma")
-    assert route(192, 64, 3, 1) == ("mfma", "mfma", "miopen")               # too many (co, ci) block groups for the weight gradient
+    assert route(192, 64, 3, 1) == ("mfma", "mfma", "mfma")                 # reg2d conv6: on the matrix cores too (no MIOpen operation left)
     assert route(8, 8, 5, 1) is None and route(8, 8, 7, 2) is None          # shapes nobody here handles: plain F.conv2d
     dev = torch.device("cuda:0")
     x = torch.randn(1, 8, 16, 16, device=dev)
