@@ -209,13 +209,19 @@ template <int C> struct BinTile;
 #ifndef MVSTER_C8_LW          // tuning hooks (tools/probes/owner_sweep.sh builds variants); the defaults are the measured best
 #define MVSTER_C8_LW 4
 #endif
+#ifndef MVSTER_C8_LH
+#define MVSTER_C8_LH 3
+#endif
 #ifndef MVSTER_C8_KPT          // swept on MI355X in round 2, DTU stage 4, B = 4, noise / scene, ms per backward:
 #define MVSTER_C8_KPT 2        //   16x8 tile: KPT 1 4.96/4.30, 2 4.45/3.73, 3 4.57/3.93, 4 4.91/4.01, 6 5.76/4.84
 #endif                         //   8x8: KPT 2 4.62/3.86, 3 4.85/3.85, 4 5.04/4.11;  32x8: KPT 2 5.45/4.51, 3 7.03/6.02
+//                             // round 3 (one item per sample; owner kernel alone, ms): 16x8 1.94; 8x4 (one wave per tile)
+//                             //   KPT 2 / 3 / 4 2.25 / 2.10 / 2.14; 8x8 2.28; 16x4 2.36 -- smaller tiles also cost the
+//                             //   count / fill passes more distinct bins per workgroup (tools/probes/ab_owner.sh)
 #ifndef MVSTER_OWNER_KPT
 #define MVSTER_OWNER_KPT 8
 #endif
-template <> struct BinTile<8> { static constexpr int kLw = MVSTER_C8_LW, kLh = 3; };     // 16 x 8
+template <> struct BinTile<8> { static constexpr int kLw = MVSTER_C8_LW, kLh = MVSTER_C8_LH; };     // 16 x 8
 template <> struct BinTile<16> { static constexpr int kLw = 4, kLh = 3; };    // 16 x 8
 template <> struct BinTile<32> { static constexpr int kLw = 4, kLh = 3; };    // 16 x 8
 template <> struct BinTile<64> { static constexpr int kLw = 3, kLh = 3; };    //  8 x 8
@@ -309,7 +315,7 @@ __device__ __forceinline__ void unpack_item(int item, int& x, int& y, int& d) {
 // Bin (within one (batch, view)) of a sample; listed = at least one tap inside the map and the position finite.
 // entry: where the bin lives in a workgroup's direct-mapped LDS table (BinAgg below).
 constexpr int kAggViews = 4;          // views whose tables are live together
-constexpr int kAggEntries = 128;      // 8 tile columns x 4 tile rows x 4 categories
+constexpr int kAggEntries = 128;      // 8 tile columns x 4 tile rows x 4 categories (2 views x 512 entries measured slower)
 __device__ __forceinline__ int sample_bin(const Landing& l, const BinGrid& bg, bool& listed, int& entry) {
     listed = (l.x0in | l.x1in) & (l.y0in | l.y1in) & !l.bad;
     const int xc = max(l.ix, 0), yc = max(l.iy, 0);            // ix, iy >= -1 for a listed sample
