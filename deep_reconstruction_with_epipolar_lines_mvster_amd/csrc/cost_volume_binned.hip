@@ -391,8 +391,11 @@ struct __attribute__((aligned(16))) StagedRec {
     float dw[8];            // coef[group(c)] * ref[c]
 };
 
+#ifndef MVSTER_C8_OWNER_WAVES
+#define MVSTER_C8_OWNER_WAVES 1
+#endif
 template <int G, int D>
-__global__ void __launch_bounds__(OwnerTile<8>::NT)
+__global__ void __launch_bounds__(OwnerTile<8>::NT, MVSTER_C8_OWNER_WAVES)
 tile_owner_c8_kernel(OwnerArgs a) {
     constexpr int C = 8;
     using T = OwnerTile<C>;
@@ -471,7 +474,13 @@ tile_owner_c8_kernel(OwnerArgs a) {
         for (int j = 0; j < KPT; ++j) {
             cell[j] = -1;
             if (id[j] >= 0) {
+#ifdef MVSTER_PROBE_OWNER_NO_PROJECT
+                Landing l{};
+                l.ix = x0 + ((px[j] + id[j]) & (TW - 1)); l.iy = y0 + ((py[j] + (id[j] >> 4)) & (TH - 1)); l.fx = hyp[j] * 1e-3f; l.fy = 0.5f;
+                l.x0in = l.x1in = l.y0in = l.y1in = true; l.bad = false;
+#else
                 const Landing l = land(q, rotate_pixel(q, (float)px[j], (float)py[j]), hyp[j], dm.Hs, dm.Ws);
+#endif
                 const int cx = l.ix - x0 + 1, cy = l.iy - y0 + 1;
                 weights_from_fraction(l.fx, l.fy, landing_mask(l), rec[j].w);
                 const float rv[C] = {r0[j].x, r0[j].y, r0[j].z, r0[j].w, r1[j].x, r1[j].y, r1[j].z, r1[j].w};
@@ -514,7 +523,13 @@ tile_owner_c8_kernel(OwnerArgs a) {
         lds_barrier();
 
         // ---- walk: LDS only ------------------------------------------------------------------------------------------------
+#ifdef MVSTER_PROBE_OWNER_NO_WALK            // timing probes (tools/probes/ab_owner.sh); results are wrong when defined
+        const int mine = 0, first = 0;
+#elif defined(MVSTER_PROBE_OWNER_EVEN_WALK)
+        const int mine = owner ? (min(CHUNK, n - c0) + NCELL - 1) / NCELL : 0, first = 0;          // every owner walks the mean count
+#else
         const int mine = owner ? cnt[tid] : 0, first = owner ? start[tid] : 0;
+#endif
         for (int k = 0; k < mine; ++k) {
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(&sorted[first + k]);
             const float4 w = rp[0], d0 = rp[1], d1 = rp[2];
