@@ -774,6 +774,19 @@ def main():
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]},
             "kernels": kernels,
         }
+        # the forward kernels' own ceiling is not HBM but the L1 / texture path: every (sample, view) pulls four taps of C
+        # floats into registers (tools/probes/gather_probe.hip measures what that path delivers for this access pattern)
+        fwd_rows = [r for r in rows if r["entry"] == "mvster_cost_volume_fwd"]
+        if fwd_rows:
+            f0 = max(fwd_rows, key=lambda r: r["total_ms"])
+            gathered = 4.0 * f0["C"] * 4 * f0["B"] * f0["HW"] * f0["D"] * f0["S"]
+            out["gather_path"] = {
+                "kernel": "mvster_cost_volume_fwd [B%d C%d G%d D%d px%d S%d]" % (f0["B"], f0["C"], f0["G"], f0["D"], f0["HW"], f0["S"]),
+                "bytes_into_registers_per_launch": gathered, "avg_launch_ms": round(f0["avg_ms"], 4),
+                "achieved_TBps": round(gathered / (f0["avg_ms"] * 1e-3) / 1e12, 2),
+                "measured_ceiling_TBps": "10.5-16.2 (profiles/r3_gather_probe.txt: the same 128 B per sample gathered with no arithmetic, "
+                                         "by address pattern)",
+                "note": "informational: roofline above prices the dominant entry against HBM as the contract asks"}
         if world == 1 and not args.no_e2e and other is None:
             # after and outside the timed region; frees the hot-path inputs first
             stages.clear()

@@ -305,9 +305,10 @@ def test_dtu_stage_forward_backward_vs_oracle(dev, stage):
     idx = out["attn_weight"].max(1)[1].cpu()
     match = float((idx == want["argmax_index"]).float().mean())
     print("    [parity] stage%d arg-max index match rate through the stub regnet: %.6f" % (stage + 1, match))
-    # white-noise features + a x8 logit gain: near-ties flip on ~1e-4 volume differences; the index is
-    # bit-exact given identical logits (test_regress_*), here we bound the flip rate
-    assert match > 0.999
+    # white-noise features + a x8 logit gain: near-ties flip on ~1e-6 logit differences; the index is bit-exact given
+    # identical logits (test_regress_*).  Measured on MI355X: 1.000000 at all four stages (the sample positions round like
+    # the reference's); the bound leaves room for one flip in 10,000 pixels (the oracle's CPU kernels vary by host)
+    assert match > 0.9999
     same = idx == want["argmax_index"]
     assert torch.equal(out["depth"].cpu()[same], want["depth"][same])
     (out["attn_weight"] * lw.to(dev)).sum().backward()
