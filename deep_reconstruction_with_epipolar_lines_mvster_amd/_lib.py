@@ -60,6 +60,7 @@ PROTOTYPES = {
     "mvster_fpn_merge_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_fpn_merge_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvster_fpn_head_gather_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mvster_fpn_head_gather_fwd_layout": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvster_fpn_head_gather_bwd": [_vp, _vp, _i, _i, _i, _vp],
     "mvster_conv_mfma_supported": [_i, _i, _i, _i],
     "mvster_conv_mfma_workspace": [_i, _i, _i, _i, _i, _i, _i, _i],
@@ -70,6 +71,7 @@ PROTOTYPES = {
     "mvster_conv_mfma_transposed": [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_conv_direct_supported": [_i, _i, _i],
     "mvster_conv_direct_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "mvster_conv_direct_fwd_layout": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_conv_direct_wgrad_workspace": [_i, _i, _i, _i, _i, _i],
     "mvster_conv_direct_wgrad": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_geometric_consistency": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp],

@@ -25,6 +25,7 @@ namespace mvster {
 
 struct ConvDims {
     int N, CIN, H, W;
+    int out_nhwc;            // forward: y is [N,H,W,COUT]
 };
 
 // PX horizontally adjacent output pixels per lane.  PX = 2 (COUT >= 16): the K x (K+1) input window is loaded once and the two
@@ -74,6 +75,19 @@ conv_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt
 #pragma unroll
                     for (int j = 0; j < PX; ++j) acc[co][j] = fmaf(v[ky * WIN + kx + j], wv, acc[co][j]);
                 }
+    }
+    if constexpr (COUT % 4 == 0) {
+        if (dm.out_nhwc) {                   // channels-last: the lane's COUT sums of a pixel are one contiguous run
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                if (xx + j >= dm.W) continue;
+                float4* __restrict__ yp = reinterpret_cast<float4*>(y + ((size_t)n * HW + (size_t)yy * dm.W + xx + j) * COUT);
+#pragma unroll
+                for (int c4 = 0; c4 < COUT / 4; ++c4)
+                    yp[c4] = make_float4(acc[4 * c4][j], acc[4 * c4 + 1][j], acc[4 * c4 + 2][j], acc[4 * c4 + 3][j]);
+            }
+            return;
+        }
     }
     float* __restrict__ yb = y + (size_t)n * COUT * HW + (size_t)yy * dm.W + xx;
 #pragma unroll
@@ -284,11 +298,18 @@ extern "C" int mvster_conv_direct_supported(int CIN, int COUT, int K) {
 
 extern "C" int mvster_conv_direct_fwd(const float* x, const float* wt, const float* bias, float* y, int N, int CIN, int COUT,
                                       int H, int W, int K, mvster_stream_t stream) {
+    return mvster_conv_direct_fwd_layout(x, wt, bias, y, N, CIN, COUT, H, W, K, MVSTER_LAYOUT_NCHW, stream);
+}
+
+extern "C" int mvster_conv_direct_fwd_layout(const float* x, const float* wt, const float* bias, float* y, int N, int CIN,
+                                             int COUT, int H, int W, int K, int out_layout, mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(wt); MVSTER_REQUIRE_PTR(y);
     MVSTER_REQUIRE_SHAPE(N > 0 && N <= 65535 && CIN > 0 && COUT > 0 && H > 0 && W > 0 && (long long)H * W <= kMaxPlane);
+    MVSTER_REQUIRE_SHAPE(out_layout == MVSTER_LAYOUT_NCHW || out_layout == MVSTER_LAYOUT_NHWC);
     if (!mvster_conv_direct_supported(CIN, COUT, K)) return MVSTER_ERR_UNSUPPORTED;
-    const ConvDims dm{N, CIN, H, W};
+    if (out_layout == MVSTER_LAYOUT_NHWC && COUT % 4 != 0) return MVSTER_ERR_UNSUPPORTED;
+    const ConvDims dm{N, CIN, H, W, out_layout == MVSTER_LAYOUT_NHWC ? 1 : 0};
     const hipStream_t st = as_stream(stream);
     switch (COUT) {
         MVSTER_CONV_CASE(1) MVSTER_CONV_CASE(3) MVSTER_CONV_CASE(4) MVSTER_CONV_CASE(8)

@@ -41,6 +41,7 @@ struct MfDims {
     int CinPad, CoutPad;              // packed weights [CinPad][K*K][CoutPad]
     int tiles_x, tiles_y;
     int depth, Creal;                 // depth > 0: the Cin = 3 * Creal input channels are VIRTUAL, see input_plane()
+    int out_nhwc;                     // forward kernels: y is [N,Ho,Wo,Cout] (the layout the cost-volume kernels gather from)
 };
 
 // (3,3,3) layers over depth slices stacked into the batch (sample n = b * depth + d): input channel cv = dz * Creal + c of
@@ -197,6 +198,22 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
     for (int r = 0; r < 2; ++r) {
         const int oy = ty * kMfRowsFwd + 2 * wave + r;
         if (oy >= d.Ho || ox >= d.Wo) continue;
+        if (d.out_nhwc) {                                          // channels-last: registers 4j .. 4j+3 = four consecutive channels
+            float* __restrict__ yp = y + (((size_t)n * d.Ho + oy) * d.Wo + ox) * d.Cout;       // (Cout % 4 == 0, checked by the host)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = co0 + nb * 32 + 8 * j + 4 * h;
+                    if (co >= d.Cout) continue;
+                    float4 v = make_float4(acc[r][nb][4 * j], acc[r][nb][4 * j + 1], acc[r][nb][4 * j + 2], acc[r][nb][4 * j + 3]);
+                    if (bias != nullptr) {
+                        v.x += bias[co]; v.y += bias[co + 1]; v.z += bias[co + 2]; v.w += bias[co + 3];
+                    }
+                    *reinterpret_cast<float4*>(yp + co) = v;
+                }
+            continue;
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -878,16 +895,17 @@ extern "C" long long mvster_conv_mfma_workspace(int N, int Cin, int Cout, int H,
 // pack_mode: see conv_mfma_pack_kernel; depth > 0: Cin = 3 * Creal virtual input channels over depth-shifted samples
 static int conv_mfma_fwd_impl(const float* x, const float* weight, const float* bias, float* y, float* workspace,
                               long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride,
-                              int pack_mode, int depth, int Creal, mvster_stream_t stream) {
+                              int pack_mode, int depth, int Creal, int out_nhwc, mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(weight); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(workspace);
+    if (out_nhwc && Cout % 4 != 0) return MVSTER_ERR_UNSUPPORTED;  // 16-byte channel groups
     MVSTER_REQUIRE_SHAPE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (long long)H * W <= kMaxPlane);
     if (!mvster_conv_mfma_supported(Cin, Cout, K, stride)) return MVSTER_ERR_UNSUPPORTED;
     MVSTER_REQUIRE_SHAPE(pack_mode == 0 || stride == 1);
     MVSTER_REQUIRE_SHAPE(workspace_floats >= mvster_conv_mfma_workspace(N, Cin, Cout, H, W, K, stride, MVSTER_CONV_OP_FWD));
     const int P = K / 2, cb = stride == 1 ? MVSTER_MF_CB_S1 : 4;
     MfDims d;
-    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.depth = depth; d.Creal = Creal;
+    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.depth = depth; d.Creal = Creal; d.out_nhwc = out_nhwc ? 1 : 0;
     d.Ho = (H + 2 * P - K) / stride + 1;
     d.Wo = (W + 2 * P - K) / stride + 1;
     d.CinPad = (Cin + cb - 1) / cb * cb;
@@ -916,9 +934,10 @@ static int conv_mfma_fwd_impl(const float* x, const float* weight, const float* 
 
 extern "C" int mvster_conv_mfma_fwd(const float* x, const float* weight, const float* bias, float* y, float* workspace,
                                     long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride,
-                                    int flip, mvster_stream_t stream) {
-    return conv_mfma_fwd_impl(x, weight, bias, y, workspace, workspace_floats, N, Cin, Cout, H, W, K, stride, flip ? 1 : 0, 0, 0,
-                              stream);
+                                    int flags, mvster_stream_t stream) {
+    MVSTER_REQUIRE_SHAPE((flags & ~(MVSTER_CONV_FLAG_FLIP | MVSTER_CONV_FLAG_OUT_NHWC)) == 0);
+    return conv_mfma_fwd_impl(x, weight, bias, y, workspace, workspace_floats, N, Cin, Cout, H, W, K, stride,
+                              flags & MVSTER_CONV_FLAG_FLIP ? 1 : 0, 0, 0, flags & MVSTER_CONV_FLAG_OUT_NHWC, stream);
 }
 
 extern "C" int mvster_conv_mfma_depth3_fwd(const float* x, const float* weight, const float* bias, float* y, float* workspace,
@@ -927,8 +946,8 @@ extern "C" int mvster_conv_mfma_depth3_fwd(const float* x, const float* weight, 
     MVSTER_REQUIRE_SHAPE(depth > 0 && N > 0 && N % depth == 0 && C > 0 && Cout > 0 && (K == 1 || K == 3));
     // forward: 3*C virtual channels of x -> Cout.  Input gradient: x := dy [N,Cout,..], 3*Cout virtual channels -> C.
     if (input_gradient)
-        return conv_mfma_fwd_impl(x, weight, nullptr, y, workspace, workspace_floats, N, 3 * Cout, C, H, W, K, 1, 3, depth, Cout, stream);
-    return conv_mfma_fwd_impl(x, weight, bias, y, workspace, workspace_floats, N, 3 * C, Cout, H, W, K, 1, 0, depth, C, stream);
+        return conv_mfma_fwd_impl(x, weight, nullptr, y, workspace, workspace_floats, N, 3 * Cout, C, H, W, K, 1, 3, depth, Cout, 0, stream);
+    return conv_mfma_fwd_impl(x, weight, bias, y, workspace, workspace_floats, N, 3 * C, Cout, H, W, K, 1, 0, depth, C, 0, stream);
 }
 
 #define MVSTER_MFMA_TR(KS_, NB_, CB_) \
@@ -946,7 +965,7 @@ extern "C" int mvster_conv_mfma_transposed(const float* x, const float* weight, 
     MVSTER_REQUIRE_SHAPE((Ho + 2 * P - K) / 2 + 1 == H && (Wo + 2 * P - K) / 2 + 1 == W);
     const int cb = K == 3 ? 8 : 4;
     MfDims d;
-    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.Ho = Ho; d.Wo = Wo; d.depth = 0; d.Creal = 0;
+    d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.Ho = Ho; d.Wo = Wo; d.depth = 0; d.Creal = 0; d.out_nhwc = 0;
     d.CinPad = (Cin + cb - 1) / cb * cb;
     d.CoutPad = (Cout + 31) / 32 * 32;
     const long long packed = (long long)d.CinPad * K * K * d.CoutPad;

@@ -289,7 +289,11 @@ tile_owner_kernel(OwnerArgs a) {
         lds_barrier();
 
         // ---- every owner walks its samples, eight channels at a time ---------------------------------------------------
+#ifdef MVSTER_PROBE_OWNER_NO_WALK            // timing probe (tools/probes/ab_owner.sh); results are wrong when defined
+        const int mine = 0, first = 0;
+#else
         const int mine = owner ? cnt[tid] : 0, first = owner ? start[tid] : 0;
+#endif
         for (int ch = 0; ch < C; ch += CH) {
             float acc[4][CH];
 #pragma unroll

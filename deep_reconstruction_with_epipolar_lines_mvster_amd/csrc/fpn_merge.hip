@@ -236,6 +236,7 @@ constexpr int kHeadLw = 20, kHeadLh = 8;       // low-resolution window of a til
 struct HeadDims {
     int N, h, w, H, W;
     float sy, sx;
+    int out_nhwc;            // forward: out is [N,H,W,8]
 };
 
 constexpr int kHeadWin = kHeadLh * kHeadLw;
@@ -293,6 +294,8 @@ fpn_head_gather_fwd_kernel(const float* __restrict__ g, const float* __restrict_
     };
     fetch(0);
     const size_t o = (size_t)n * kHeadCo * HW + (size_t)Y * dm.W + X;
+    float res[kHeadCo];                                            // channels-last output: the pixel's eight sums, stored together
+#pragma unroll
     for (int co = 0; co < kHeadCo; ++co) {
         float* __restrict__ w = &win[co & 1][0][0];
 #pragma unroll
@@ -309,7 +312,13 @@ fpn_head_gather_fwd_kernel(const float* __restrict__ g, const float* __restrict_
             for (int kx = 0; kx < 3; ++kx)
                 acc += (wgt[ky][kx][0] * w[off[ky][kx][0]] + wgt[ky][kx][1] * w[off[ky][kx][1]]) +
                        (wgt[ky][kx][2] * w[off[ky][kx][2]] + wgt[ky][kx][3] * w[off[ky][kx][3]]);
-        if (live) out[o + (size_t)co * HW] = acc;
+        res[co] = acc;
+        if (live && !dm.out_nhwc) out[o + (size_t)co * HW] = acc;
+    }
+    if (live && dm.out_nhwc) {
+        float4* __restrict__ op = reinterpret_cast<float4*>(out + ((size_t)n * HW + (size_t)Y * dm.W + X) * kHeadCo);
+        op[0] = make_float4(res[0], res[1], res[2], res[3]);
+        op[1] = make_float4(res[4], res[5], res[6], res[7]);
     }
 }
 
@@ -438,10 +447,17 @@ extern "C" int mvster_fpn_merge_bwd(const float* dy, const float* skip, const fl
 
 extern "C" int mvster_fpn_head_gather_fwd(const float* g, const float* base, float* out, int N, int h, int w,
                                           mvster_stream_t stream) {
+    return mvster_fpn_head_gather_fwd_layout(g, base, out, N, h, w, MVSTER_LAYOUT_NCHW, stream);
+}
+
+extern "C" int mvster_fpn_head_gather_fwd_layout(const float* g, const float* base, float* out, int N, int h, int w,
+                                                 int out_layout, mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(g); MVSTER_REQUIRE_PTR(base); MVSTER_REQUIRE_PTR(out);
     MVSTER_REQUIRE_SHAPE(N > 0 && N <= 65535 && h > 1 && w > 1 && (long long)4 * h * w <= kMaxPlane);
-    const HeadDims dm{N, h, w, 2 * h, 2 * w, (float)(h - 1) / (float)(2 * h - 1), (float)(w - 1) / (float)(2 * w - 1)};
+    MVSTER_REQUIRE_SHAPE(out_layout == MVSTER_LAYOUT_NCHW || (out_layout == MVSTER_LAYOUT_NHWC && out != base));
+    const HeadDims dm{N, h, w, 2 * h, 2 * w, (float)(h - 1) / (float)(2 * h - 1), (float)(w - 1) / (float)(2 * w - 1),
+                      out_layout == MVSTER_LAYOUT_NHWC ? 1 : 0};
     const dim3 grid(((dm.W + kHeadTw - 1) / kHeadTw) * ((dm.H + kHeadTh - 1) / kHeadTh), N);
     hipLaunchKernelGGL(fpn_head_gather_fwd_kernel, grid, dim3(kBlock), 0, as_stream(stream), g, base, out, dm);
     return launch_status();
@@ -451,7 +467,7 @@ extern "C" int mvster_fpn_head_gather_bwd(const float* dy, float* dg, int N, int
     using namespace mvster;
     MVSTER_REQUIRE_PTR(dy); MVSTER_REQUIRE_PTR(dg);
     MVSTER_REQUIRE_SHAPE(N > 0 && (long long)N * kHeadCo <= 65535 && h > 1 && w > 1 && (long long)4 * h * w <= kMaxPlane);
-    const HeadDims dm{N, h, w, 2 * h, 2 * w, (float)(h - 1) / (float)(2 * h - 1), (float)(w - 1) / (float)(2 * w - 1)};
+    const HeadDims dm{N, h, w, 2 * h, 2 * w, (float)(h - 1) / (float)(2 * h - 1), (float)(w - 1) / (float)(2 * w - 1), 0};
     const dim3 grid(((w + kUpTw - 1) / kUpTw) * ((h + kUpTh - 1) / kUpTh), N * kHeadCo);
     hipLaunchKernelGGL(fpn_head_gather_bwd_kernel, grid, dim3(kBlock), 0, as_stream(stream), dy, dg, dm);
     return launch_status();

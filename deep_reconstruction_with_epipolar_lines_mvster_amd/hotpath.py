@@ -204,7 +204,10 @@ COUNT_IN_FORWARD = True     # training forward also counts the samples per desti
 class _FusedCostVolume(torch.autograd.Function):
     """Feature maps may arrive NCHW-contiguous (the reference's FPN output) or channels_last.  The kernels
     gather from channels-last storage: NCHW inputs are converted once per call (and their gradients converted
-    back), channels_last inputs are used in place and receive channels_last gradients."""
+    back), channels_last inputs are used in place; channels_last LEAVES receive channels_last gradients (their .grad
+    matches them), channels_last maps produced by another operator (FPN4's output layers) receive NCHW-contiguous
+    gradients on the binned route -- written as planes by the kernels themselves, the layout every upstream backward
+    kernel of this package reads."""
 
     @staticmethod
     def forward(ctx, pose, hypo, attn_temp, G, layout, ref, *srcs):
@@ -215,6 +218,7 @@ class _FusedCostVolume(torch.autograd.Function):
         feats = (ref,) + tuple(srcs)
         if layout == _lib.LAYOUT_NHWC:
             was_cl = [_is_channels_last(f) for f in feats]
+            ctx.cl_leaf = any(cl and f.is_leaf for cl, f in zip(was_cl, (ref,) + tuple(srcs)))
             todo = [i for i, f in enumerate(feats) if not f.is_contiguous(memory_format=torch.channels_last)]
             if todo:                                        # all planar maps of the stage in one launch
                 done = _convert_many([feats[i].contiguous() for i in todo], to_nhwc=True)
@@ -224,6 +228,7 @@ class _FusedCostVolume(torch.autograd.Function):
                 feats = tuple(feats)
         else:
             was_cl = [False] * len(feats)
+            ctx.cl_leaf = False
             feats = tuple(f.contiguous() for f in feats)
         vol = torch.empty(B, G, D, H, W, dtype=torch.float32, device=ref.device)
         wsum = torch.empty(B, D, H, W, dtype=torch.float32, device=ref.device)
@@ -271,7 +276,7 @@ class _FusedCostVolume(torch.autograd.Function):
             need = B * S * H * W * D * G
         ws = torch.empty(need, dtype=torch.float32, device=ref.device) if need > 0 else None
         # every leaf NCHW and the owner kernels run: they (and the coefficient kernel) write the gradients as planes directly
-        planar_grads = (PLANAR_GRADS and layout == _lib.LAYOUT_NHWC and not any(was_cl) and
+        planar_grads = (PLANAR_GRADS and layout == _lib.LAYOUT_NHWC and not ctx.cl_leaf and
                         _lib.bwd_route(S, B, C, G, D, H, W, Hs, Ws, layout, need)[1] == "binned")
         if planar_grads:
             grads = [torch.empty(f.shape, dtype=torch.float32, device=f.device) for f in feats]

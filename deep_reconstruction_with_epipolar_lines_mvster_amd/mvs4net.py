@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .hotpath import stagenet, init_range, init_inverse_range, schedule_inverse_range, _on, _stream
+from .hotpath import stagenet, init_range, init_inverse_range, schedule_inverse_range, to_planar, _on, _stream
 
 __all__ = ["MVS4net", "FPN4", "reg2d", "mono_depth_decoder"]
 
@@ -228,26 +228,31 @@ class _DirectConv2d(torch.autograd.Function):
     ``route`` None: the direct kernels with their own per-operation policy (the few-channel stride-1 layers)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride=1, route=None):
+    def forward(ctx, x, weight, bias, stride=1, route=None, out_channels_last=False):
+        """``out_channels_last``: y [N,Cout,Ho,Wo] is stored as [N,Ho,Wo,Cout] (torch.channels_last) by the kernel itself --
+        FPN4's output layers hand the cost-volume kernels the layout they gather from (HIP routes, Cout % 4 == 0)."""
         N, Cin, H, W = x.shape
         Cout, _, K, _ = weight.shape
         impl = "direct" if route is None else route[0]
         dev = x.device
+        fmt = torch.channels_last if out_channels_last else torch.contiguous_format
         if impl == "miopen":
-            y = F.conv2d(x, weight, bias, stride, K // 2)
+            y = F.conv2d(x, weight, bias, stride, K // 2).contiguous(memory_format=fmt)
         elif impl == "mfma":
             Ho, Wo = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
-            y = torch.empty(N, Cout, Ho, Wo, dtype=torch.float32, device=dev)
+            y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=dev, memory_format=fmt)
             ws, need = _mfma_workspace(_lib.load(), dev, N, Cin, Cout, H, W, K, stride, 0)
             with _on(dev):
                 _lib.call("mvster_conv_mfma_fwd", x.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
-                          y.data_ptr(), ws.data_ptr(), need, N, Cin, Cout, H, W, K, stride, 0, _stream(dev))
+                          y.data_ptr(), ws.data_ptr(), need, N, Cin, Cout, H, W, K, stride, 2 if out_channels_last else 0,
+                          _stream(dev))
         else:
-            y = torch.empty(N, Cout, H, W, dtype=torch.float32, device=dev)
+            y = torch.empty((N, Cout, H, W), dtype=torch.float32, device=dev, memory_format=fmt)
             wt = weight.detach().permute(1, 2, 3, 0).contiguous()                  # [Cin, K, K, Cout]
             with _on(dev):
-                _lib.call("mvster_conv_direct_fwd", x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None,
-                          y.data_ptr(), N, Cin, Cout, H, W, K, _stream(dev))
+                _lib.call("mvster_conv_direct_fwd_layout", x.data_ptr(), wt.data_ptr(),
+                          bias.data_ptr() if bias is not None else None, y.data_ptr(), N, Cin, Cout, H, W, K,
+                          _lib.LAYOUT_NHWC if out_channels_last else _lib.LAYOUT_NCHW, _stream(dev))
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.stride = stride
@@ -309,7 +314,7 @@ class _DirectConv2d(torch.autograd.Function):
                 else:
                     _, dweight, dbias = _miopen_backward(dy, x, weight, stride, [False, True, ctx.has_bias],
                                                          [Cout] if ctx.has_bias else None)
-        return dx, dweight, dbias, None, None
+        return dx, dweight, dbias, None, None, None
 
 
 class _MfmaDepthConv(torch.autograd.Function):
@@ -452,8 +457,9 @@ def _conv_route(Cin, Cout, K, stride):
     return None if route == ("miopen", "miopen", "miopen") else route
 
 
-def _conv2d(x, weight, bias=None, stride=1, padding=0):
-    """F.conv2d, routed per operation to the HIP kernels for the layers they are built for."""
+def _conv2d(x, weight, bias=None, stride=1, padding=0, out_channels_last=False):
+    """F.conv2d, routed per operation to the HIP kernels for the layers they are built for.  ``out_channels_last``: the
+    HIP forward kernels store the result as torch.channels_last (ignored on the stock route and when Cout % 4 != 0)."""
     stride = (stride, stride) if isinstance(stride, int) else tuple(stride)
     padding = (padding, padding) if isinstance(padding, int) else tuple(padding)
     K = weight.shape[2]
@@ -461,7 +467,8 @@ def _conv2d(x, weight, bias=None, stride=1, padding=0):
             and weight.shape[2] == weight.shape[3] and stride[0] == stride[1] and padding == (K // 2, K // 2)):
         route = _conv_route(weight.shape[1], weight.shape[0], K, stride[0])
         if route is not None:
-            return _DirectConv2d.apply(x, weight, bias, stride[0], route)
+            return _DirectConv2d.apply(x, weight, bias, stride[0], route,
+                                       bool(out_channels_last) and weight.shape[0] % 4 == 0 and route[0] != "miopen")
     return F.conv2d(x, weight, bias, stride, padding)
 
 
@@ -519,11 +526,13 @@ class _HeadGather(torch.autograd.Function):
     """out = base + sum over the nine taps of the shifted, x2-upsampled planes of g (csrc/fpn_merge.hip, head gather)."""
 
     @staticmethod
-    def forward(ctx, g, base):
+    def forward(ctx, g, base, out_channels_last=False):
         N, _, h, w = g.shape
-        out = torch.empty_like(base)
+        out = torch.empty(base.shape, dtype=torch.float32, device=base.device,
+                          memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
         with _on(g.device):
-            _lib.call("mvster_fpn_head_gather_fwd", g.data_ptr(), base.data_ptr(), out.data_ptr(), N, h, w, _stream(g.device))
+            _lib.call("mvster_fpn_head_gather_fwd_layout", g.data_ptr(), base.data_ptr(), out.data_ptr(), N, h, w,
+                      _lib.LAYOUT_NHWC if out_channels_last else _lib.LAYOUT_NCHW, _stream(g.device))
         ctx.lowres = (N, h, w)
         return out
 
@@ -537,13 +546,17 @@ class _HeadGather(torch.autograd.Function):
             dg = torch.empty(N, 72, h, w, dtype=torch.float32, device=dy.device)
             with _on(dy.device):
                 _lib.call("mvster_fpn_head_gather_bwd", dy.data_ptr(), dg.data_ptr(), N, h, w, _stream(dy.device))
-        return dg, dy
+        return dg, dy, None
 
 
 _FUSED_HEAD = True           # FPN4's last level without its 64-channel full-resolution map (needs the HIP convolutions)
+_FPN_EMITS_CHANNELS_LAST = True   # out1 .. out4 store their maps as torch.channels_last (the kernels' own epilogues): the
+#                                 # cost-volume kernels gather from them in place, no nchw_to_nhwc pass per stage; the
+#                                 # gradients come back as planes (hotpath._FusedCostVolume), which is what the layers'
+#                                 # backward kernels read
 
 
-def _top_level_head(feat, skip, lateral, head):
+def _top_level_head(feat, skip, lateral, head, out_channels_last=False):
     """``head(F.interpolate(feat, x2, bilinear, align_corners=True) + lateral(skip))`` for a 1x1 ``lateral`` and a 3x3
     bias-free ``head`` with 8 output channels, when nothing else needs the merged map (FPN4's last level,
     models/mvs4net_utils.py:500-505).  Both steps are linear: the head's channel contraction is applied to ``feat`` at LOW
@@ -558,7 +571,7 @@ def _top_level_head(feat, skip, lateral, head):
     wc = torch.einsum("ocyx,ci->oiyx", w4, wi).contiguous()                # [8, Cs, 3, 3]
     g = _conv2d(feat, wg.contiguous(), bg, 1, 0)
     base = _conv2d(skip, wc, None, 1, 1)
-    return _HeadGather.apply(g, base)
+    return _HeadGather.apply(g, base, out_channels_last)
 
 
 def _pyramid_level(cin, cout, downsample):
@@ -602,7 +615,8 @@ class FPN4(nn.Module):
                 x = block(x, groups)
             skips.append(x)
         feat = skips[3]
-        head_conv = lambda m, t: _conv2d(t, m.weight, m.bias, m.stride, m.padding)
+        cl = _FPN_EMITS_CHANNELS_LAST and x.is_cuda
+        head_conv = lambda m, t: _conv2d(t, m.weight, m.bias, m.stride, m.padding, out_channels_last=cl)
         outs = {"stage1": head_conv(self.out1, feat)}
         for k, (lateral, head) in enumerate(((self.inner1, self.out2), (self.inner2, self.out3), (self.inner3, self.out4))):
             skip = skips[2 - k]
@@ -610,7 +624,7 @@ class FPN4(nn.Module):
                     and feat.dtype == torch.float32 and feat.is_contiguous() and skip.is_contiguous() and head.bias is None
                     and tuple(head.weight.shape[:1] + head.weight.shape[2:]) == (8, 3, 3) and feat.shape[2] > 1 and feat.shape[3] > 1
                     and tuple(skip.shape[2:]) == (2 * feat.shape[2], 2 * feat.shape[3])):
-                outs["stage4"] = _top_level_head(feat, skip, lateral, head)      # the merged map is not needed any further
+                outs["stage4"] = _top_level_head(feat, skip, lateral, head, cl)  # the merged map is not needed any further
                 break
             feat = _top_down_merge(feat, skip, lateral)
             outs["stage%d" % (k + 2)] = head_conv(head, feat)
@@ -690,6 +704,27 @@ class reg2d(nn.Module):
         return y.view(B, D, H, W)
 
 
+class _PlanarCopy(torch.autograd.Function):
+    """NCHW-contiguous copy of a channels_last map (csrc/layout.hip); the gradient passes through unchanged (autograd
+    does not tie a gradient's strides to its tensor's).  The mono head reads the reference view's maps as planes while
+    the cost-volume kernels gather from the channels-last originals: one view's copy instead of a conversion of all N."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return to_planar(t)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy
+
+
+def _as_planes(t):
+    if t.is_cuda and t.dim() == 4 and t.dtype == torch.float32 and not t.is_contiguous() \
+            and t.is_contiguous(memory_format=torch.channels_last):
+        return _PlanarCopy.apply(t)
+    return t
+
+
 class mono_depth_decoder(nn.Module):
     """Auxiliary monocular depth head on the reference-view features (models/mvs4net_utils.py:840-882)."""
 
@@ -703,10 +738,11 @@ class mono_depth_decoder(nn.Module):
     def forward(self, outputs, d_min, d_max, debug=0):
         lo = (1 / d_max)[:, None, None, None]
         hi = (1 / d_min)[:, None, None, None]
+        feats = {i: _as_planes(outputs["stage%d" % i]["mono_feat"]) for i in (1, 2, 3, 4)}
         for i in (1, 2, 3):
-            coarse = self.convblocks[i - 1](outputs["stage%d" % i]["mono_feat"])
+            coarse = self.convblocks[i - 1](feats[i])
             coarse = F.interpolate(coarse, scale_factor=2, mode=self.interpol)
-            fine = outputs["stage%d" % (i + 1)]["mono_feat"]
+            fine = feats[i + 1]
             last = self.conv3x3[i - 1]
             disp = self.sigmoid(_conv2d(torch.cat([coarse, fine], 1), last.weight, last.bias, last.stride, last.padding))
             outputs["stage%d" % (i + 1)]["mono_depth"] = (1 / (lo + (hi - lo) * disp)).squeeze(1)

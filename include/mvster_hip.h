@@ -327,8 +327,12 @@ int mvster_bn_eval_fwd_nhwc(const float *x, const float *gamma, const float *bet
  * and this operator gathers, per output pixel, the nine shifted bilinear samples:
  *   out[n,co,Y,X] = base[n,co,Y,X] + sum_{ky,kx : (Y+ky-1, X+kx-1) inside} bilinear_x2(g[n, co*9+ky*3+kx])(Y+ky-1, X+kx-1)
  *   g [N,72,h,w]   base, out, dy [N,8,2h,2w] (base = the 8 -> 8 layer on conv0 with the composed weights; out may alias base)
+ *   _fwd_layout: out_layout = MVSTER_LAYOUT_NHWC writes out as [N,2h,2w,8] (then out must NOT alias base) -- the stage-4
+ *         feature map in the layout the cost-volume kernels gather from; MVSTER_LAYOUT_NCHW = mvster_fpn_head_gather_fwd.
  *   _bwd: dg [N,72,h,w] from dy (d base = dy). */
 int mvster_fpn_head_gather_fwd(const float *g, const float *base, float *out, int N, int h, int w, mvster_stream_t stream);
+int mvster_fpn_head_gather_fwd_layout(const float *g, const float *base, float *out, int N, int h, int w, int out_layout,
+                                      mvster_stream_t stream);
 int mvster_fpn_head_gather_bwd(const float *dy, float *dg, int N, int h, int w, mvster_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
@@ -337,8 +341,10 @@ int mvster_fpn_head_gather_bwd(const float *dy, float *dg, int N, int h, int w, 
  * slices in FPN4 (models/mvs4net_utils.py:441-455,466-470) and reg2d (models/mvs4net_utils.py:891-899).
  *   x [N,Cin,H,W]   y, dy [N,Cout,Ho,Wo] with Ho = (H + 2*(K/2) - K) / stride + 1 (same for Wo)
  *   mvster_conv_mfma_fwd : y = conv(x, weight [Cout,Cin,K,K]) (+ bias [Cout], may be NULL).
- *       flip = 1 (stride 1 only): `weight` is [Cin,Cout,K,K] and its taps are mirrored -- with x := dy of a stride-1
- *       layer and Cin/Cout swapped this is that layer's input gradient.
+ *       flags & MVSTER_CONV_FLAG_FLIP (stride 1 only): `weight` is [Cin,Cout,K,K] and its taps are mirrored -- with
+ *       x := dy of a stride-1 layer and Cin/Cout swapped this is that layer's input gradient.
+ *       flags & MVSTER_CONV_FLAG_OUT_NHWC (Cout % 4 == 0): y is written channels-last, [N,Ho,Wo,Cout] -- FPN4's out1 / out2
+ *       hand their maps to the cost-volume kernels in the layout those gather from, no conversion pass in between.
  *   mvster_conv_mfma_wgrad : dweight [Cout,Cin,K,K] = sum over n, pixels of dy (x) x-window.  (For a transposed
  *       convolution layer pass x := the layer's dy, dy := the layer's x, Cin/Cout swapped: the result is its
  *       [Cin,Cout,K,K] weight gradient.)  No atomics: bitwise reproducible.
@@ -347,10 +353,12 @@ int mvster_fpn_head_gather_bwd(const float *dy, float *dg, int N, int h, int w, 
 #define MVSTER_CONV_OP_FWD 0
 #define MVSTER_CONV_OP_WGRAD 1
 #define MVSTER_CONV_OP_TRANSPOSED 2     /* mvster_conv_mfma_transposed (pass stride = 2): its packing differs from the forward's */
+#define MVSTER_CONV_FLAG_FLIP 1
+#define MVSTER_CONV_FLAG_OUT_NHWC 2
 int mvster_conv_mfma_supported(int Cin, int Cout, int K, int stride);
 long long mvster_conv_mfma_workspace(int N, int Cin, int Cout, int H, int W, int K, int stride, int op);
 int mvster_conv_mfma_fwd(const float *x, const float *weight, const float *bias, float *y, float *workspace,
-                         long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride, int flip,
+                         long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride, int flags,
                          mvster_stream_t stream);
 int mvster_conv_mfma_wgrad(const float *x, const float *dy, float *dweight, float *workspace, long long workspace_floats,
                            int N, int Cin, int Cout, int H, int W, int K, int stride, mvster_stream_t stream);
@@ -400,6 +408,8 @@ int mvster_fpn_merge_bwd(const float *dy, const float *skip, const float *weight
  *   mvster_conv_direct_fwd   : y[n,co] = bias[co] + sum_{ci,tap} wt[ci][tap][co] * x[n,ci, . + tap]
  *        x [N,CIN,H,W]   wt [CIN,K*K,COUT] (the weight [COUT,CIN,K,K] permuted; for the INPUT gradient pass dy as x and the
  *        flipped weight permuted to [COUT,K*K,CIN])   bias [COUT] or NULL   y [N,COUT,H,W].  COUT in {1,3,4,8,16,32,64}.
+ *   mvster_conv_direct_fwd_layout : the same with y in out_layout; MVSTER_LAYOUT_NHWC (COUT % 4 == 0) writes [N,H,W,COUT]
+ *        (FPN4's out3 feeding the cost-volume kernels), MVSTER_LAYOUT_NCHW = mvster_conv_direct_fwd.
  *   mvster_conv_direct_wgrad : dweight [COUT,CIN,K,K] (+ dbias [COUT] unless NULL) from x and dy; workspace of
  *        mvster_conv_direct_wgrad_workspace(...) floats holds per-tile partial sums (no atomics, reproducible).
  *        COUT*K <= 256 and COUT <= 32, else MVSTER_ERR_UNSUPPORTED.
@@ -407,6 +417,8 @@ int mvster_fpn_merge_bwd(const float *dy, const float *skip, const float *weight
 int mvster_conv_direct_supported(int CIN, int COUT, int K);
 int mvster_conv_direct_fwd(const float *x, const float *wt, const float *bias, float *y, int N, int CIN, int COUT, int H,
                            int W, int K, mvster_stream_t stream);
+int mvster_conv_direct_fwd_layout(const float *x, const float *wt, const float *bias, float *y, int N, int CIN, int COUT,
+                                  int H, int W, int K, int out_layout, mvster_stream_t stream);
 long long mvster_conv_direct_wgrad_workspace(int N, int CIN, int COUT, int H, int W, int K);
 int mvster_conv_direct_wgrad(const float *x, const float *dy, float *dweight, float *dbias, float *workspace,
                              long long workspace_floats, int N, int CIN, int COUT, int H, int W, int K,

@@ -138,3 +138,56 @@ def test_top_level_head_matches_the_operator_sequence(N, h, w):
     _close(lateral.weight.grad, lat64.weight.grad, tag + " d/d inner3.weight", rel=2e-5)
     _close(lateral.bias.grad, lat64.bias.grad, tag + " d/d inner3.bias", rel=2e-5)
     _close(head.weight.grad, head64.weight.grad, tag + " d/d out4.weight", rel=2e-5)
+
+
+def test_output_layers_store_channels_last_with_identical_values():
+    """out1 .. out4 write their maps as torch.channels_last from the kernels' own epilogues (matrix-core 1x1 /
+    3x3, direct 3x3, the head gather): same bits as the NCHW stores, the layout the cost-volume kernels gather from, and
+    the backward (which receives planes) is unchanged."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    net = mvs4net.FPN4(8).to(dev).train()
+    x = torch.rand(3, 3, 72, 104, device=dev)
+    res = {}
+    real_call = mvs4net._lib.call
+    for cl in (True, False):
+        mvs4net._FPN_EMITS_CHANNELS_LAST = cl
+        calls = []
+        mvs4net._lib.call = lambda name, *a: (calls.append((name, a)), real_call(name, *a))[1]
+        try:
+            net.zero_grad(set_to_none=True)
+            y = net(x)
+            gy = {k: torch.randn(v.shape, generator=torch.Generator().manual_seed(len(k) + v.shape[1])).to(dev) for k, v in y.items()}
+            sum((y[k] * gy[k]).sum() for k in y).backward()
+            res[cl] = ({k: v.detach() for k, v in y.items()}, {n: p.grad.clone() for n, p in net.named_parameters()}, calls)
+        finally:
+            mvs4net._FPN_EMITS_CHANNELS_LAST = True
+            mvs4net._lib.call = real_call
+    for k, v in res[True][0].items():
+        assert v.is_contiguous(memory_format=torch.channels_last) and not v.is_contiguous(), k
+        assert res[False][0][k].is_contiguous(), k
+        assert torch.equal(v, res[False][0][k]), k
+    # the four producers ran with the channels-last flag: two matrix-core layers (out1, out2), one direct layer (out3), the gather
+    names = [(n, a) for n, a in res[True][2]]
+    assert sum(1 for n, a in names if n == "mvster_conv_mfma_fwd" and a[-2] == 2) == 2
+    assert sum(1 for n, a in names if n == "mvster_conv_direct_fwd_layout" and a[-2] == mvs4net._lib.LAYOUT_NHWC) == 1
+    assert sum(1 for n, a in names if n == "mvster_fpn_head_gather_fwd_layout" and a[-2] == mvs4net._lib.LAYOUT_NHWC) == 1
+    for n in res[True][1]:
+        _close(res[True][1][n], res[False][1][n], "grad " + n, rel=1e-6)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,K,H,W,impl", [(2, 64, 64, 1, 19, 45, "mfma"), (1, 64, 32, 3, 21, 70, "mfma"), (2, 24, 20, 3, 9, 33, "mfma"),
+                                                   (2, 64, 16, 3, 18, 37, "direct"), (1, 8, 8, 3, 30, 65, "direct"), (3, 16, 4, 1, 7, 9, "direct")])
+def test_convolution_kernels_write_channels_last(N, Cin, Cout, K, H, W, impl):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    w = (0.2 * torch.randn(Cout, Cin, K, K, generator=g)).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    route = (impl, impl, impl)
+    a = mvs4net._DirectConv2d.apply(x, w, b, 1, route, False)
+    c = mvs4net._DirectConv2d.apply(x, w, b, 1, route, True)
+    assert c.shape == a.shape and c.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(a, c)
+    want = F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), 1, K // 2)
+    _close(c, want, "%s %d->%d k%d channels-last" % (impl, Cin, Cout, K), rel=2e-5)

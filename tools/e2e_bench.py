@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--ddp", action="store_true",
                     help="wrap the model in DistributedDataParallel over RCCL like train_mvs4.py:562-570 (one process per GPU; "
                          "start with torch.distributed.run, with --gpus N, or alone for a one-rank group)")
+    ap.add_argument("--fpn-nchw", action="store_true", help="FPN4's output layers store NCHW maps (round-2 behaviour: one "
+                    "layout-conversion launch per stage in the hot path)")
     ap.add_argument("--gpus", type=int, default=1,
                     help="with --ddp and no launcher: start this many ranks (one per GPU) through bench.launch_ranks")
     args = ap.parse_args()
@@ -57,6 +59,7 @@ def main():
     torch.backends.cudnn.benchmark = args.benchmark
     from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net as _m
     _m._BN_IMPL = args.bn
+    _m._FPN_EMITS_CHANNELS_LAST = not args.fpn_nchw
     torch.manual_seed(0)
     B, N, H, W = args.batch, args.views, args.height, args.width
     model = mv.MVS4net(arch_mode="fpn", reg_net="reg2d", num_stage=4, fpn_base_channel=8, reg_channel=8,
