@@ -64,6 +64,7 @@ PROTOTYPES = {
     "mvster_fpn_head_gather_bwd": [_vp, _vp, _i, _i, _i, _vp],
     "mvster_conv_mfma_supported": [_i, _i, _i, _i],
     "mvster_conv_mfma_workspace": [_i, _i, _i, _i, _i, _i, _i, _i],
+    "mvster_conv_mfma_packed_floats": [_i, _i, _i, _i, _i],
     "mvster_conv_mfma_fwd": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_conv_mfma_wgrad": [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_conv_mfma_depth3_fwd": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -72,6 +73,12 @@ PROTOTYPES = {
     "mvster_conv_direct_supported": [_i, _i, _i],
     "mvster_conv_direct_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_conv_direct_fwd_layout": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvster_conv_direct_fwd_ep": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "mvster_bn_eval_prepare": [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp],
+    "mvster_bn_eval_norm_floats": [_i],
+    "mvster_conv_mfma_pack": [_vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
+    "mvster_conv_mfma_fwd_ep": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "mvster_conv_mfma_transposed_ep": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "mvster_conv_direct_wgrad_workspace": [_i, _i, _i, _i, _i, _i],
     "mvster_conv_direct_wgrad": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp],
     "mvster_geometric_consistency": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp],
@@ -81,7 +88,8 @@ PROTOTYPES = {
 
 RESTYPES = {"mvster_cost_volume_bwd_workspace": _ll, "mvster_cost_volume_bwd_route_workspace": _ll,
             "mvster_cost_volume_bin_counts": _ll, "mvster_conv_direct_wgrad_workspace": _ll,
-            "mvster_conv_mfma_workspace": _ll, "mvster_sinkhorn_generic_workspace": _ll}      # everything else returns the int status
+            "mvster_conv_mfma_workspace": _ll, "mvster_sinkhorn_generic_workspace": _ll,
+            "mvster_conv_mfma_packed_floats": _ll, "mvster_bn_eval_norm_floats": _ll}      # everything else returns the int status
 
 MVSTER_OK = 0
 LAYOUT_NCHW = 0

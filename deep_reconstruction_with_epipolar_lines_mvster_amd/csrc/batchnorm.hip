@@ -10,6 +10,7 @@
 //   Algorithmic bytes: 3T forward, 5T backward for a tensor of T bytes.
 #include <math.h>
 
+#include "conv_epilogue.h"
 #include "mvster_device.h"
 #include "mvster_host.h"
 
@@ -391,6 +392,19 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
     mean_out[c] = running_mean[c];
 }
 
+// the same coefficients as three padded arrays a | b | mean for the convolution epilogues (conv_epilogue.h)
+__global__ void bn_eval_norm_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                    float* __restrict__ norm, int C, int Cpad, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cpad) return;
+    const bool real = c < C;
+    const float g = real && gamma != nullptr ? gamma[c] : 1.0f;
+    norm[c] = real ? g * (float)(1.0 / sqrt((double)running_var[c] + (double)eps)) : 0.0f;
+    norm[Cpad + c] = real && beta != nullptr ? beta[c] : 0.0f;
+    norm[2 * Cpad + c] = real ? running_mean[c] : 0.0f;
+}
+
 static int check_bn_nhwc(long long M, int C) {
     MVSTER_REQUIRE_SHAPE(M > 0 && M <= (1LL << 31) - 1 && C > 0);
     if (C % 4 != 0 || C > 64 || 64 % (C / 4) != 0) return MVSTER_ERR_UNSUPPORTED;    // C in {4, 8, 16, 32, 64}
@@ -521,6 +535,19 @@ extern "C" int mvster_bn_eval_fwd(const float* x, const float* gamma, const floa
     dim3 grid(grid_for(HW, kBlock * kBnVec * kBnIters), C, N);
     if (relu) hipLaunchKernelGGL((bn_apply_kernel<true>), grid, dim3(kBlock), 0, st, x, affine, mean, residual, y, C, HW, N);
     else hipLaunchKernelGGL((bn_apply_kernel<false>), grid, dim3(kBlock), 0, st, x, affine, mean, residual, y, C, HW, N);
+    return launch_status();
+}
+
+extern "C" long long mvster_bn_eval_norm_floats(int C) { return C > 0 ? 3LL * mvster::conv_norm_pad(C) : 0; }
+
+extern "C" int mvster_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                      float* norm, int C, float eps, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(running_mean); MVSTER_REQUIRE_PTR(running_var); MVSTER_REQUIRE_PTR(norm);
+    MVSTER_REQUIRE_SHAPE(C > 0 && C <= 65535);
+    const int Cpad = conv_norm_pad(C);
+    hipLaunchKernelGGL(bn_eval_norm_kernel, dim3(grid_for(Cpad, 64)), dim3(64), 0, as_stream(stream), gamma, beta, running_mean,
+                       running_var, norm, C, Cpad, eps);
     return launch_status();
 }
 

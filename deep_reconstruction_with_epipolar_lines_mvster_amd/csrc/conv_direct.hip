@@ -18,6 +18,7 @@
 // COUT channels) sits in LDS, the input channels go by one at a time with their haloed tile; thread (co, row of taps)
 // walks the pixels of the tile with 3 running sums; partial sums per tile are reduced by a second tiny kernel
 // (no atomics, bitwise reproducible).
+#include "conv_epilogue.h"
 #include "mvster_device.h"
 #include "mvster_host.h"
 
@@ -26,13 +27,14 @@ namespace mvster {
 struct ConvDims {
     int N, CIN, H, W;
     int out_nhwc;            // forward: y is [N,H,W,COUT]
+    ConvEpilogue ep;         // inference: BatchNorm (running statistics) + ReLU + skip connection on the accumulator
 };
 
 // PX horizontally adjacent output pixels per lane.  PX = 2 (COUT >= 16): the K x (K+1) input window is loaded once and the two
 // accumulator sets pair up into packed FMAs -- the many-accumulator cases (the 8->64 input gradient of the 64->8 layer,
 // 64->16, 48->16) are bound by FMA issue: 0.57 -> 0.37, 0.26 -> 0.21, 0.62 -> 0.43 ms.  PX = 1 (COUT <= 8): those layers are
 // bound by memory and want the lanes (64->8 forward 0.34 ms with one pixel per lane, 0.46 with two).
-template <int COUT, int K, int PX>
+template <int COUT, int K, int PX, bool EP>
 __global__ void __launch_bounds__(kBlock)
 conv_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
                        float* __restrict__ y, ConvDims dm) {
@@ -76,25 +78,47 @@ conv_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt
                     for (int j = 0; j < PX; ++j) acc[co][j] = fmaf(v[ky * WIN + kx + j], wv, acc[co][j]);
                 }
     }
+    if constexpr (EP) {                      // inference: BatchNorm (running statistics) + ReLU on the way out; wave-uniform
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {  // coefficients: scalar loads
+            const NormCoef k{dm.ep.norm[co], dm.ep.norm[dm.ep.Cpad + co], dm.ep.norm[2 * dm.ep.Cpad + co]};
+#pragma unroll
+            for (int j = 0; j < PX; ++j) acc[co][j] = normalise(k, acc[co][j], dm.ep.relu != 0);
+        }
+    }
     if constexpr (COUT % 4 == 0) {
         if (dm.out_nhwc) {                   // channels-last: the lane's COUT sums of a pixel are one contiguous run
 #pragma unroll
             for (int j = 0; j < PX; ++j) {
                 if (xx + j >= dm.W) continue;
-                float4* __restrict__ yp = reinterpret_cast<float4*>(y + ((size_t)n * HW + (size_t)yy * dm.W + xx + j) * COUT);
+                const size_t idx = ((size_t)n * HW + (size_t)yy * dm.W + xx + j) * COUT;
 #pragma unroll
-                for (int c4 = 0; c4 < COUT / 4; ++c4)
-                    yp[c4] = make_float4(acc[4 * c4][j], acc[4 * c4 + 1][j], acc[4 * c4 + 2][j], acc[4 * c4 + 3][j]);
+                for (int c4 = 0; c4 < COUT / 4; ++c4) {
+                    float4 v = make_float4(acc[4 * c4][j], acc[4 * c4 + 1][j], acc[4 * c4 + 2][j], acc[4 * c4 + 3][j]);
+                    if constexpr (EP) {
+                        if (dm.ep.residual != nullptr) {
+                            const float4 rs = reinterpret_cast<const float4*>(dm.ep.residual + idx)[c4];
+                            v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+                        }
+                    }
+                    reinterpret_cast<float4*>(y + idx)[c4] = v;
+                }
             }
             return;
         }
     }
-    float* __restrict__ yb = y + (size_t)n * COUT * HW + (size_t)yy * dm.W + xx;
+    const size_t base = (size_t)n * COUT * HW + (size_t)yy * dm.W + xx;
 #pragma unroll
     for (int co = 0; co < COUT; ++co)
 #pragma unroll
         for (int j = 0; j < PX; ++j)
-            if (xx + j < dm.W) yb[(size_t)co * HW + j] = acc[co][j];
+            if (xx + j < dm.W) {
+                float v = acc[co][j];
+                if constexpr (EP) {
+                    if (dm.ep.residual != nullptr) v += dm.ep.residual[base + (size_t)co * HW + j];
+                }
+                y[base + (size_t)co * HW + j] = v;
+            }
 }
 
 // ---- weight gradient ------------------------------------------------------------------------------------------------
@@ -291,8 +315,15 @@ extern "C" int mvster_conv_direct_supported(int CIN, int COUT, int K) {
     case CO: {                                                                                                              \
         constexpr int PX = CO >= 16 ? 2 : 1;                                                                                \
         const dim3 grid(grid_for((long long)H * ((W + PX - 1) / PX), kBlock), N);                                           \
-        if (K == 3) hipLaunchKernelGGL((conv_direct_fwd_kernel<CO, 3, PX>), grid, dim3(kBlock), 0, st, x, wt, bias, y, dm); \
-        else hipLaunchKernelGGL((conv_direct_fwd_kernel<CO, 1, PX>), grid, dim3(kBlock), 0, st, x, wt, bias, y, dm);      \
+        if constexpr (CO <= 16) {            /* the epilogue's coefficients sit in scalar registers: few-channel layers only */ \
+            if (norm != nullptr) {                                                                                          \
+                if (K == 3) hipLaunchKernelGGL((conv_direct_fwd_kernel<CO, 3, PX, true>), grid, dim3(kBlock), 0, st, x, wt, bias, y, dm); \
+                else hipLaunchKernelGGL((conv_direct_fwd_kernel<CO, 1, PX, true>), grid, dim3(kBlock), 0, st, x, wt, bias, y, dm); \
+                break;                                                                                                      \
+            }                                                                                                               \
+        }                                                                                                                   \
+        if (K == 3) hipLaunchKernelGGL((conv_direct_fwd_kernel<CO, 3, PX, false>), grid, dim3(kBlock), 0, st, x, wt, bias, y, dm); \
+        else hipLaunchKernelGGL((conv_direct_fwd_kernel<CO, 1, PX, false>), grid, dim3(kBlock), 0, st, x, wt, bias, y, dm);      \
         break;                                                                                                              \
     }
 
@@ -303,13 +334,23 @@ extern "C" int mvster_conv_direct_fwd(const float* x, const float* wt, const flo
 
 extern "C" int mvster_conv_direct_fwd_layout(const float* x, const float* wt, const float* bias, float* y, int N, int CIN,
                                              int COUT, int H, int W, int K, int out_layout, mvster_stream_t stream) {
+    return mvster_conv_direct_fwd_ep(x, wt, bias, y, N, CIN, COUT, H, W, K, out_layout, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mvster_conv_direct_fwd_ep(const float* x, const float* wt, const float* bias, float* y, int N, int CIN, int COUT,
+                                         int H, int W, int K, int out_layout, const float* norm, const float* residual, int relu,
+                                         mvster_stream_t stream) {
     using namespace mvster;
     MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(wt); MVSTER_REQUIRE_PTR(y);
     MVSTER_REQUIRE_SHAPE(N > 0 && N <= 65535 && CIN > 0 && COUT > 0 && H > 0 && W > 0 && (long long)H * W <= kMaxPlane);
     MVSTER_REQUIRE_SHAPE(out_layout == MVSTER_LAYOUT_NCHW || out_layout == MVSTER_LAYOUT_NHWC);
     if (!mvster_conv_direct_supported(CIN, COUT, K)) return MVSTER_ERR_UNSUPPORTED;
     if (out_layout == MVSTER_LAYOUT_NHWC && COUT % 4 != 0) return MVSTER_ERR_UNSUPPORTED;
-    const ConvDims dm{N, CIN, H, W, out_layout == MVSTER_LAYOUT_NHWC ? 1 : 0};
+    // the epilogue exists for the few-channel layers the policy routes here (COUT <= 16); without `norm` neither ReLU nor
+    // the residual is applied by the plain kernels
+    if ((norm != nullptr && COUT > 16) || (norm == nullptr && (residual != nullptr || relu))) return MVSTER_ERR_UNSUPPORTED;
+    const ConvDims dm{N, CIN, H, W, out_layout == MVSTER_LAYOUT_NHWC ? 1 : 0,
+                      ConvEpilogue{norm, residual, relu ? 1 : 0, conv_norm_pad(COUT)}};
     const hipStream_t st = as_stream(stream);
     switch (COUT) {
         MVSTER_CONV_CASE(1) MVSTER_CONV_CASE(3) MVSTER_CONV_CASE(4) MVSTER_CONV_CASE(8)

@@ -20,6 +20,7 @@
 //   Both tiles stay plane-major in LDS; a plane stride of (32/CIB) * odd words makes the 32 (kx,ci) columns of a lane group
 //   fall on 32 different banks.  Waves split the tile's rows, workgroups are persistent over tiles, partial sums are folded
 //   through LDS per workgroup and across workgroups by a second small kernel (no atomics: bitwise reproducible).
+#include "conv_epilogue.h"
 #include "mvster_device.h"
 #include "mvster_host.h"
 
@@ -42,6 +43,7 @@ struct MfDims {
     int tiles_x, tiles_y;
     int depth, Creal;                 // depth > 0: the Cin = 3 * Creal input channels are VIRTUAL, see input_plane()
     int out_nhwc;                     // forward kernels: y is [N,Ho,Wo,Cout] (the layout the cost-volume kernels gather from)
+    ConvEpilogue ep;                  // forward / transposed kernels: inference BatchNorm + ReLU + skip connection on the accumulator
 };
 
 // (3,3,3) layers over depth slices stacked into the batch (sample n = b * depth + d): input channel cv = dz * Creal + c of
@@ -93,7 +95,7 @@ struct FwdTile {
     static constexpr int WPS = round_to_residue(KK * COW, 64, 32);
 };
 
-template <int KS, int S, int NB, int CB>
+template <int KS, int S, int NB, int CB, bool EP>
 __global__ void __launch_bounds__(kBlock)
 #if MVSTER_MF_FWD_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(MVSTER_MF_FWD_WAVES)))
@@ -192,37 +194,63 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
             }
         }
     }
-    // D: column (pixel) = lane & 31, row (output channel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // D: column (pixel) = lane & 31, row (output channel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): registers
+    // 4j .. 4j+3 hold four consecutive channels.  EP: the layer's BatchNorm / ReLU / skip connection on the way out.
     const int ox = tx * kMfTileW + p;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int oy = ty * kMfRowsFwd + 2 * wave + r;
-        if (oy >= d.Ho || ox >= d.Wo) continue;
-        if (d.out_nhwc) {                                          // channels-last: registers 4j .. 4j+3 = four consecutive channels
-            float* __restrict__ yp = y + (((size_t)n * d.Ho + oy) * d.Wo + ox) * d.Cout;       // (Cout % 4 == 0, checked by the host)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + nb * 32 + 8 * j + 4 * h;
+            float add[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (bias != nullptr) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int co = co0 + nb * 32 + 8 * j + 4 * h;
-                    if (co >= d.Cout) continue;
-                    float4 v = make_float4(acc[r][nb][4 * j], acc[r][nb][4 * j + 1], acc[r][nb][4 * j + 2], acc[r][nb][4 * j + 3]);
-                    if (bias != nullptr) {
-                        v.x += bias[co]; v.y += bias[co + 1]; v.z += bias[co + 2]; v.w += bias[co + 3];
-                    }
-                    *reinterpret_cast<float4*>(yp + co) = v;
-                }
-            continue;
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int co = co0 + nb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (co < d.Cout)
-                    y[(((size_t)n * d.Cout + co) * d.Ho + oy) * d.Wo + ox] = acc[r][nb][i] + (bias != nullptr ? bias[co] : 0.0f);
+                for (int e = 0; e < 4; ++e) add[e] = co + e < d.Cout ? bias[co + e] : 0.0f;
             }
-    }
+            float4 ka = {}, kb = {}, km = {};
+            if constexpr (EP) {                                    // (padded to a multiple of 32 channels: always in bounds)
+                ka = *reinterpret_cast<const float4*>(d.ep.norm + co);
+                kb = *reinterpret_cast<const float4*>(d.ep.norm + d.ep.Cpad + co);
+                km = *reinterpret_cast<const float4*>(d.ep.norm + 2 * d.ep.Cpad + co);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int oy = ty * kMfRowsFwd + 2 * wave + r;
+                if (oy >= d.Ho || ox >= d.Wo) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[r][nb][4 * j + e] + add[e];
+                if constexpr (EP) {
+                    v[0] = normalise(NormCoef{ka.x, kb.x, km.x}, v[0], d.ep.relu != 0);
+                    v[1] = normalise(NormCoef{ka.y, kb.y, km.y}, v[1], d.ep.relu != 0);
+                    v[2] = normalise(NormCoef{ka.z, kb.z, km.z}, v[2], d.ep.relu != 0);
+                    v[3] = normalise(NormCoef{ka.w, kb.w, km.w}, v[3], d.ep.relu != 0);
+                }
+                if (d.out_nhwc) {                                  // channels-last (Cout % 4 == 0, checked by the host)
+                    if (co >= d.Cout) continue;
+                    const size_t idx = (((size_t)n * d.Ho + oy) * d.Wo + ox) * d.Cout + co;
+                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                    if constexpr (EP) {
+                        if (d.ep.residual != nullptr) {
+                            const float4 rs = *reinterpret_cast<const float4*>(d.ep.residual + idx);
+                            o.x += rs.x; o.y += rs.y; o.z += rs.z; o.w += rs.w;
+                        }
+                    }
+                    *reinterpret_cast<float4*>(y + idx) = o;
+                    continue;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (co + e >= d.Cout) continue;
+                    const size_t idx = (((size_t)n * d.Cout + co + e) * d.Ho + oy) * d.Wo + ox;
+                    float o = v[e];
+                    if constexpr (EP) {
+                        if (d.ep.residual != nullptr) o += d.ep.residual[idx];
+                    }
+                    y[idx] = o;
+                }
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------- transposed convolution, stride 2
@@ -243,7 +271,7 @@ struct TrTile {
     static constexpr int WPS = round_to_residue(KK * COW, 64, 32);
 };
 
-template <int KS, int NB, int CB>
+template <int KS, int NB, int CB, bool EP>
 __global__ void __launch_bounds__(kBlock)
 conv_mfma_transposed_kernel(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, MfDims d) {
     using T = TrTile<KS, NB, CB>;
@@ -342,22 +370,56 @@ conv_mfma_transposed_kernel(const float* __restrict__ x, const float* __restrict
         }
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int oy = oy0 + 2 * wave + r;
-        if (oy >= d.Ho) continue;
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int ox = ox0 + 2 * p + q;
-            if (ox >= d.Wo) continue;
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + nb * 32 + 8 * j + 4 * h;          // registers 4j .. 4j+3: four consecutive channels
+            float4 ka = {}, kb = {}, km = {};
+            if constexpr (EP) {
+                ka = *reinterpret_cast<const float4*>(d.ep.norm + co);
+                kb = *reinterpret_cast<const float4*>(d.ep.norm + d.ep.Cpad + co);
+                km = *reinterpret_cast<const float4*>(d.ep.norm + 2 * d.ep.Cpad + co);
+            }
+            const float fa[4] = {ka.x, ka.y, ka.z, ka.w}, fb[4] = {kb.x, kb.y, kb.z, kb.w}, fm[4] = {km.x, km.y, km.z, km.w};
+            // a lane holds the horizontally adjacent outputs 2p and 2p + 1 (q = 0, 1): one 8-byte store (and skip-connection
+            // load) per pair where the row is even-sized, instead of two half-used passes over every cache line
+            const bool pairs = (d.Wo & 1) == 0;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int r = 0; r < 2; ++r) {
+                const int oy = oy0 + 2 * wave + r;
+                const int ox = ox0 + 2 * p;
+                if (oy >= d.Ho || ox >= d.Wo) continue;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int co = co0 + nb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (co < d.Cout) y[(((size_t)n * d.Cout + co) * d.Ho + oy) * d.Wo + ox] = acc[r][q][nb][i];
+                for (int e = 0; e < 4; ++e) {
+                    if (co + e >= d.Cout) continue;
+                    const size_t idx = (((size_t)n * d.Cout + co + e) * d.Ho + oy) * d.Wo + ox;
+                    float v0 = acc[r][0][nb][4 * j + e], v1 = acc[r][1][nb][4 * j + e];
+                    if constexpr (EP) {
+                        v0 = normalise(NormCoef{fa[e], fb[e], fm[e]}, v0, d.ep.relu != 0);
+                        v1 = normalise(NormCoef{fa[e], fb[e], fm[e]}, v1, d.ep.relu != 0);
+                    }
+                    if (pairs) {                                   // ox even, Wo even: idx is even, ox + 1 < Wo
+                        if constexpr (EP) {
+                            if (d.ep.residual != nullptr) {
+                                const float2 rs = *reinterpret_cast<const float2*>(d.ep.residual + idx);
+                                v0 += rs.x;
+                                v1 += rs.y;
+                            }
+                        }
+                        *reinterpret_cast<float2*>(y + idx) = make_float2(v0, v1);
+                    } else {
+                        if constexpr (EP) {
+                            if (d.ep.residual != nullptr) {
+                                v0 += d.ep.residual[idx];
+                                if (ox + 1 < d.Wo) v1 += d.ep.residual[idx + 1];
+                            }
+                        }
+                        y[idx] = v0;
+                        if (ox + 1 < d.Wo) y[idx + 1] = v1;
+                    }
                 }
+            }
         }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
@@ -889,23 +951,45 @@ extern "C" long long mvster_conv_mfma_workspace(int N, int Cin, int Cout, int H,
     return (long long)((Cin + cb - 1) / cb * cb) * K * K * ((Cout + 31) / 32 * 32);
 }
 
-#define MVSTER_MFMA_FWD(KS_, S_, NB_, CB_) \
-    hipLaunchKernelGGL((conv_mfma_fwd_kernel<KS_, S_, NB_, CB_>), grid, dim3(kBlock), 0, st, x, workspace, bias, y, d)
+#define MVSTER_MFMA_FWD(KS_, S_, NB_, CB_)                                                                                    \
+    do {                                                                                                                         \
+        if (d.ep.norm != nullptr)                                                                                             \
+            hipLaunchKernelGGL((conv_mfma_fwd_kernel<KS_, S_, NB_, CB_, true>), grid, dim3(kBlock), 0, st, x, wp, bias, y, d);  \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((conv_mfma_fwd_kernel<KS_, S_, NB_, CB_, false>), grid, dim3(kBlock), 0, st, x, wp, bias, y, d); \
+    } while (0)
+
+namespace mvster {
+struct EpilogueArgs {         // host side of ConvEpilogue
+    const float* norm;
+    const float* residual;
+    int relu;
+    int prepacked;            // `weight` is the array mvster_conv_mfma_pack wrote: no pack launch, no workspace
+};
+static ConvEpilogue make_epilogue(const EpilogueArgs* e, int Cout) {
+    return e != nullptr ? ConvEpilogue{e->norm, e->residual, e->relu ? 1 : 0, conv_norm_pad(Cout)}
+                        : ConvEpilogue{nullptr, nullptr, 0, conv_norm_pad(Cout)};
+}
+}  // namespace mvster
 
 // pack_mode: see conv_mfma_pack_kernel; depth > 0: Cin = 3 * Creal virtual input channels over depth-shifted samples
 static int conv_mfma_fwd_impl(const float* x, const float* weight, const float* bias, float* y, float* workspace,
                               long long workspace_floats, int N, int Cin, int Cout, int H, int W, int K, int stride,
-                              int pack_mode, int depth, int Creal, int out_nhwc, mvster_stream_t stream) {
+                              int pack_mode, int depth, int Creal, int out_nhwc, mvster_stream_t stream,
+                              const mvster::EpilogueArgs* ep = nullptr) {
     using namespace mvster;
-    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(weight); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(workspace);
+    const bool prepacked = ep != nullptr && ep->prepacked;
+    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(weight); MVSTER_REQUIRE_PTR(y);
+    if (!prepacked) MVSTER_REQUIRE_PTR(workspace);
     if (out_nhwc && Cout % 4 != 0) return MVSTER_ERR_UNSUPPORTED;  // 16-byte channel groups
     MVSTER_REQUIRE_SHAPE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (long long)H * W <= kMaxPlane);
     if (!mvster_conv_mfma_supported(Cin, Cout, K, stride)) return MVSTER_ERR_UNSUPPORTED;
     MVSTER_REQUIRE_SHAPE(pack_mode == 0 || stride == 1);
-    MVSTER_REQUIRE_SHAPE(workspace_floats >= mvster_conv_mfma_workspace(N, Cin, Cout, H, W, K, stride, MVSTER_CONV_OP_FWD));
+    MVSTER_REQUIRE_SHAPE(prepacked || workspace_floats >= mvster_conv_mfma_workspace(N, Cin, Cout, H, W, K, stride, MVSTER_CONV_OP_FWD));
     const int P = K / 2, cb = stride == 1 ? MVSTER_MF_CB_S1 : 4;
     MfDims d;
     d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.depth = depth; d.Creal = Creal; d.out_nhwc = out_nhwc ? 1 : 0;
+    d.ep = make_epilogue(ep, Cout);
     d.Ho = (H + 2 * P - K) / stride + 1;
     d.Wo = (W + 2 * P - K) / stride + 1;
     d.CinPad = (Cin + cb - 1) / cb * cb;
@@ -916,8 +1000,10 @@ static int conv_mfma_fwd_impl(const float* x, const float* weight, const float* 
     MVSTER_REQUIRE_SHAPE(tiles < (1LL << 31));
     const hipStream_t st = as_stream(stream);
     const int packed = d.CinPad * K * K * d.CoutPad;
-    hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
-                       K * K, d.CinPad, d.CoutPad, pack_mode);
+    const float* wp = prepacked ? weight : workspace;
+    if (!prepacked)
+        hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
+                           K * K, d.CinPad, d.CoutPad, pack_mode);
     const bool two = d.CoutPad % 64 == 0;                          // 64 output channels per workgroup when they divide
     if (K == 1 && d.CoutPad == 96) {                               // 1x1, 65-96 output channels (FPN4's head contraction 64 -> 72):
         const dim3 grid((unsigned)tiles, 1);                       // all three blocks from one pass over the input tile
@@ -950,14 +1036,21 @@ extern "C" int mvster_conv_mfma_depth3_fwd(const float* x, const float* weight, 
     return conv_mfma_fwd_impl(x, weight, bias, y, workspace, workspace_floats, N, 3 * C, Cout, H, W, K, 1, 0, depth, C, 0, stream);
 }
 
-#define MVSTER_MFMA_TR(KS_, NB_, CB_) \
-    hipLaunchKernelGGL((conv_mfma_transposed_kernel<KS_, NB_, CB_>), grid, dim3(kBlock), 0, st, x, workspace, y, d)
+#define MVSTER_MFMA_TR(KS_, NB_, CB_)                                                                                       \
+    do {                                                                                                                       \
+        if (d.ep.norm != nullptr)                                                                                           \
+            hipLaunchKernelGGL((conv_mfma_transposed_kernel<KS_, NB_, CB_, true>), grid, dim3(kBlock), 0, st, x, wp, y, d);   \
+        else                                                                                                                \
+            hipLaunchKernelGGL((conv_mfma_transposed_kernel<KS_, NB_, CB_, false>), grid, dim3(kBlock), 0, st, x, wp, y, d);  \
+    } while (0)
 
-extern "C" int mvster_conv_mfma_transposed(const float* x, const float* weight, float* y, float* workspace,
-                                           long long workspace_floats, int N, int Cin, int Cout, int H, int W, int Ho, int Wo,
-                                           int K, mvster_stream_t stream) {
+static int conv_mfma_transposed_impl(const float* x, const float* weight, float* y, float* workspace,
+                                     long long workspace_floats, int N, int Cin, int Cout, int H, int W, int Ho, int Wo,
+                                     int K, mvster_stream_t stream, const mvster::EpilogueArgs* ep) {
     using namespace mvster;
-    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(weight); MVSTER_REQUIRE_PTR(y); MVSTER_REQUIRE_PTR(workspace);
+    const bool prepacked = ep != nullptr && ep->prepacked;
+    MVSTER_REQUIRE_PTR(x); MVSTER_REQUIRE_PTR(weight); MVSTER_REQUIRE_PTR(y);
+    if (!prepacked) MVSTER_REQUIRE_PTR(workspace);
     MVSTER_REQUIRE_SHAPE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && (long long)Ho * Wo <= kMaxPlane);
     if (!(K == 3 || K == 5) || Cin > 1024 || Cout > 1024) return MVSTER_ERR_UNSUPPORTED;
     const int P = K / 2;
@@ -966,22 +1059,74 @@ extern "C" int mvster_conv_mfma_transposed(const float* x, const float* weight, 
     const int cb = K == 3 ? 8 : 4;
     MfDims d;
     d.N = N; d.Cin = Cin; d.Cout = Cout; d.H = H; d.W = W; d.Ho = Ho; d.Wo = Wo; d.depth = 0; d.Creal = 0; d.out_nhwc = 0;
+    d.ep = make_epilogue(ep, Cout);
     d.CinPad = (Cin + cb - 1) / cb * cb;
     d.CoutPad = (Cout + 31) / 32 * 32;
     const long long packed = (long long)d.CinPad * K * K * d.CoutPad;
-    MVSTER_REQUIRE_SHAPE(workspace_floats >= packed);
+    MVSTER_REQUIRE_SHAPE(prepacked || workspace_floats >= packed);
     d.tiles_x = (Wo + 2 * kMfTileW - 1) / (2 * kMfTileW);
     d.tiles_y = (Ho + kMfTrRows - 1) / kMfTrRows;
     const long long tiles = (long long)N * d.tiles_x * d.tiles_y;
     MVSTER_REQUIRE_SHAPE(tiles < (1LL << 31));
     const hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
-                       K * K, d.CinPad, d.CoutPad, 2);
+    const float* wp = prepacked ? weight : workspace;
+    if (!prepacked)
+        hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
+                           K * K, d.CinPad, d.CoutPad, 2);
     const bool two = d.CoutPad % 64 == 0;
     const dim3 grid((unsigned)tiles, d.CoutPad / (two ? 64 : 32));
     if (K == 3) { if (two) MVSTER_MFMA_TR(3, 2, 8); else MVSTER_MFMA_TR(3, 1, 8); }
     else { if (two) MVSTER_MFMA_TR(5, 2, 4); else MVSTER_MFMA_TR(5, 1, 4); }
     return launch_status();
+}
+
+extern "C" int mvster_conv_mfma_transposed(const float* x, const float* weight, float* y, float* workspace,
+                                           long long workspace_floats, int N, int Cin, int Cout, int H, int W, int Ho, int Wo,
+                                           int K, mvster_stream_t stream) {
+    return conv_mfma_transposed_impl(x, weight, y, workspace, workspace_floats, N, Cin, Cout, H, W, Ho, Wo, K, stream, nullptr);
+}
+
+// ---- inference entry points: BatchNorm (running statistics) + ReLU + skip connection in the epilogue, weights packed once ----
+extern "C" long long mvster_conv_mfma_packed_floats(int Cin, int Cout, int K, int stride, int op) {
+    return mvster_conv_mfma_workspace(1, Cin, Cout, 1, 1, K, stride, op == MVSTER_CONV_OP_TRANSPOSED ? op : MVSTER_CONV_OP_FWD);
+}
+
+extern "C" int mvster_conv_mfma_pack(const float* weight, float* packed, long long packed_floats, int Cin, int Cout, int K,
+                                     int stride, int op, int mode, mvster_stream_t stream) {
+    using namespace mvster;
+    MVSTER_REQUIRE_PTR(weight); MVSTER_REQUIRE_PTR(packed);
+    MVSTER_REQUIRE_SHAPE(Cin > 0 && Cout > 0 && mode >= 0 && mode <= 3 && (op == MVSTER_CONV_OP_FWD || op == MVSTER_CONV_OP_TRANSPOSED));
+    if (op == MVSTER_CONV_OP_FWD ? !mvster_conv_mfma_supported(Cin, Cout, K, stride) : !(K == 3 || K == 5)) return MVSTER_ERR_UNSUPPORTED;
+    const long long need = mvster_conv_mfma_packed_floats(Cin, Cout, K, stride, op);
+    MVSTER_REQUIRE_SHAPE(packed_floats >= need && need < (1LL << 31));
+    const int cb = op == MVSTER_CONV_OP_TRANSPOSED ? (K == 3 ? 8 : 4) : (stride == 1 ? MVSTER_MF_CB_S1 : 4);
+    const int CinPad = (Cin + cb - 1) / cb * cb, CoutPad = (Cout + 31) / 32 * 32;
+    hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(need, kBlock)), dim3(kBlock), 0, as_stream(stream), weight, packed, Cin,
+                       Cout, K * K, CinPad, CoutPad, mode);
+    return launch_status();
+}
+
+extern "C" int mvster_conv_mfma_fwd_ep(const float* x, const float* packed, const float* bias, float* y, int N, int Cin, int Cout,
+                                       int H, int W, int K, int stride, int flags, int depth, const float* norm,
+                                       const float* residual, int relu, mvster_stream_t stream) {
+    MVSTER_REQUIRE_SHAPE((flags & ~MVSTER_CONV_FLAG_OUT_NHWC) == 0 && depth >= 0);
+    MVSTER_REQUIRE_PTR(norm);
+    const mvster::EpilogueArgs ep{norm, residual, relu, 1};
+    if (depth > 0) {          // a (3,k,k) layer over depth slices stacked into the batch: Cin = 3 * C virtual channels (depth3_fwd)
+        MVSTER_REQUIRE_SHAPE(N % depth == 0 && Cin % 3 == 0 && (K == 1 || K == 3) && stride == 1);
+        return conv_mfma_fwd_impl(x, packed, bias, y, nullptr, 0, N, Cin, Cout, H, W, K, 1, 0, depth, Cin / 3,
+                                  flags & MVSTER_CONV_FLAG_OUT_NHWC, stream, &ep);
+    }
+    return conv_mfma_fwd_impl(x, packed, bias, y, nullptr, 0, N, Cin, Cout, H, W, K, stride, 0, 0, 0,
+                              flags & MVSTER_CONV_FLAG_OUT_NHWC, stream, &ep);
+}
+
+extern "C" int mvster_conv_mfma_transposed_ep(const float* x, const float* packed, float* y, int N, int Cin, int Cout, int H,
+                                              int W, int Ho, int Wo, int K, const float* norm, const float* residual, int relu,
+                                              mvster_stream_t stream) {
+    MVSTER_REQUIRE_PTR(norm);
+    const mvster::EpilogueArgs ep{norm, residual, relu, 1};
+    return conv_mfma_transposed_impl(x, packed, y, nullptr, 0, N, Cin, Cout, H, W, Ho, Wo, K, stream, &ep);
 }
 
 #define MVSTER_MFMA_WG(KS_, S_, CIB_, TH_)                                                                                   \

@@ -116,6 +116,7 @@ def _batch_norm(bn, x, relu=False, groups=1, residual=None):
     fused = (_BN_IMPL == "hip" and training and x.is_cuda and x.dtype == torch.float32
              and (x.is_contiguous() or dense_cl) and bn.momentum is not None and x.dim() >= 3)
     if fused:
+        bn.__dict__["_mvster_stats_gen"] = bn.__dict__.get("_mvster_stats_gen", 0) + 1      # see _bn_eval_norm
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
         if residual is not None and (not x.is_contiguous() or not residual.is_contiguous() or residual.shape != x.shape):
@@ -149,6 +150,88 @@ def _batch_norm(bn, x, relu=False, groups=1, residual=None):
 
 
 _BN_IMPL = "hip"             # "hip" (csrc/batchnorm.hip for training mode), "miopen" (F.batch_norm) or "native" (ATen)
+_FUSED_EVAL = True           # inference (eval mode under no_grad): convolution -> BatchNorm -> ReLU (-> + skip) as ONE kernel
+#                            # (the normalisation in the convolution's epilogue, csrc/conv_epilogue.h) and every derived
+#                            # weight array (matrix-core packing, direct-kernel permutation, BatchNorm affine) built once per
+#                            # parameter version instead of once per call
+
+
+def _cached(owner, tag, sources, build, generation=0):
+    """``build()`` once per version of the ``sources`` tensors; the result lives on the ``owner`` module (freed with it).
+    In-place updates (optimizer steps, load_state_dict) bump ``_version``, ``.to()`` / ``.data =`` change ``data_ptr``."""
+    key = (generation,) + tuple((t.data_ptr(), t._version) for t in sources if t is not None)
+    store = owner.__dict__.setdefault("_mvster_cache", {})
+    hit = store.get(tag)
+    if hit is None or hit[0] != key:
+        hit = (key, build())
+        store[tag] = hit
+    return hit[1]
+
+
+def _bn_eval_norm(bn):
+    """The coefficient array of mvster_bn_eval_prepare for an eval-mode BatchNorm module (a | b | mean, padded)."""
+    def build():
+        C = bn.num_features
+        norm = torch.empty(_lib.load().mvster_bn_eval_norm_floats(C), dtype=torch.float32, device=bn.running_mean.device)
+        opt = lambda t: t.data_ptr() if t is not None else None
+        with _on(norm.device):
+            _lib.call("mvster_bn_eval_prepare", opt(bn.weight), opt(bn.bias), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                      norm.data_ptr(), C, float(bn.eps), _stream(norm.device))
+        return norm
+    # (the training kernels update the running statistics through their pointers: no tensor version moves, hence the counter)
+    return _cached(bn, "norm", (bn.weight, bn.bias, bn.running_mean, bn.running_var), build, bn.__dict__.get("_mvster_stats_gen", 0))
+
+
+def _inference(bn, x):
+    """The fused inference path applies: eval-mode BatchNorm with running statistics, no autograd, an NCHW fp32 HIP tensor."""
+    return (_FUSED_EVAL and _BN_IMPL == "hip" and not bn.training and bn.track_running_stats and not torch.is_grad_enabled()
+            and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous())
+
+
+def _conv_bn_eval(x, owner, tag, weight2d, bias, stride, bn, relu, residual=None, depth=0):
+    """relu?(bn(conv2d(x, weight2d(), bias, stride, padding K // 2))) [+ residual] as one kernel, or None when the layer has
+    no HIP forward route (the caller then takes the unfused path).  ``weight2d``: () -> [Cout, Cin, K, K] view of
+    ``owner.weight`` (only evaluated when the derived array has to be rebuilt); ``depth`` > 0: a (3,k,k) layer over depth
+    slices stacked into the batch, weight2d() its folded [Cout, 3*C, k, k] weight, x [B*depth, C, H, W] read in place."""
+    w = owner.weight
+    N, Cx, H, W = x.shape
+    if depth > 0:
+        Cout, K = w.shape[0], w.shape[3]
+        Cin = 3 * Cx
+        impl = "mfma" if (_MFMA_CONV and _DEPTH_IN_PLACE and K == 3 and stride == 1 and Cout >= 16 and Cin <= _MFMA_MAX_WGRAD_CIN) else None
+    else:
+        Cout, K = w.shape[0], w.shape[-1]
+        Cin = Cx
+        route = _conv_route(Cin, Cout, K, stride)
+        impl = route[0] if route is not None else None
+    if impl not in ("mfma", "direct") or (residual is not None and not residual.is_contiguous()):
+        return None
+    dev = x.device
+    norm = _bn_eval_norm(bn)
+    P = K // 2
+    Ho, Wo = (H + 2 * P - K) // stride + 1, (W + 2 * P - K) // stride + 1
+    y = torch.empty(N, Cout, Ho, Wo, dtype=torch.float32, device=dev)
+    if residual is not None and residual.shape != y.shape:
+        return None
+    opt = lambda t: t.data_ptr() if t is not None else None
+    if impl == "mfma":
+        def pack():
+            w2 = weight2d().contiguous()
+            need = _lib.load().mvster_conv_mfma_packed_floats(Cin, Cout, K, stride, 0)
+            packed = torch.empty(need, dtype=torch.float32, device=dev)
+            with _on(dev):
+                _lib.call("mvster_conv_mfma_pack", w2.data_ptr(), packed.data_ptr(), need, Cin, Cout, K, stride, 0, 0, _stream(dev))
+            return packed
+        packed = _cached(owner, tag + ":mfma", (w,), pack)
+        with _on(dev):
+            _lib.call("mvster_conv_mfma_fwd_ep", x.data_ptr(), packed.data_ptr(), opt(bias), y.data_ptr(), N, Cin, Cout, H, W, K,
+                      stride, 0, depth, norm.data_ptr(), opt(residual), 1 if relu else 0, _stream(dev))
+    else:
+        wt = _cached(owner, tag + ":direct", (w,), lambda: weight2d().permute(1, 2, 3, 0).contiguous())
+        with _on(dev):
+            _lib.call("mvster_conv_direct_fwd_ep", x.data_ptr(), wt.data_ptr(), opt(bias), y.data_ptr(), N, Cin, Cout, H, W, K,
+                      _lib.LAYOUT_NCHW, norm.data_ptr(), opt(residual), 1 if relu else 0, _stream(dev))
+    return y
 
 
 class _ConvBNReLU2d(nn.Module):
@@ -161,6 +244,11 @@ class _ConvBNReLU2d(nn.Module):
 
     def forward(self, x, groups=1):
         conv = self.conv
+        if (_inference(self.bn, x) and conv.stride[0] == conv.stride[1] and conv.kernel_size[0] == conv.kernel_size[1]
+                and conv.padding == (conv.kernel_size[0] // 2,) * 2):
+            y = _conv_bn_eval(x, conv, "w", lambda: conv.weight, conv.bias, conv.stride[0], self.bn, True)
+            if y is not None:
+                return y
         return _batch_norm(self.bn, _conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), relu=True, groups=groups)
 
 
@@ -203,7 +291,30 @@ class _ConvBNReLU3d(nn.Module):
 
     def forward_slices(self, x2d, B, D):
         # BatchNorm3d over [B,C,D,H,W] == batch norm over [B*D,C,H,W]: same per-channel statistics, same parameters
-        return _batch_norm(self.bn, _conv3d_as_2d(self.conv, x2d, B, D), relu=True)
+        y = self._forward_slices_inference(x2d, B, D) if _inference(self.bn, x2d) else None
+        return y if y is not None else _batch_norm(self.bn, _conv3d_as_2d(self.conv, x2d, B, D), relu=True)
+
+    def _forward_slices_inference(self, x2d, B, D):
+        """The layer as one kernel (BatchNorm + ReLU in the convolution's epilogue), the same case split as _conv3d_as_2d."""
+        conv = self.conv
+        w = conv.weight
+        kd, k = w.shape[2], w.shape[3]
+        stride, pad = conv.stride[1:], conv.padding[1:]
+        if w.shape[3] != w.shape[4] or stride[0] != stride[1] or tuple(pad) != (k // 2, k // 2):
+            return None
+        if kd == 1:
+            return _conv_bn_eval(x2d, conv, "w2d", lambda: w[:, :, 0], conv.bias, stride[0], self.bn, True)
+        if not (kd == 3 and conv.stride[0] == 1 and conv.padding[0] == 1 and stride[0] == 1):
+            return None
+        fold = lambda: w.permute(0, 2, 1, 3, 4).reshape(w.shape[0], 3 * w.shape[1], k, k)
+        y = _conv_bn_eval(x2d, conv, "w3", fold, conv.bias, 1, self.bn, True, depth=D) if conv.bias is None else None
+        if y is not None:
+            return y
+        C, H, W = x2d.shape[1:]                # few output channels (conv0): the three depth-shifted copies, concatenated
+        x5 = x2d.view(B, D, C, H, W)
+        pad_slice = x5.new_zeros(B, 1, C, H, W)
+        stacked = torch.cat([torch.cat([pad_slice, x5[:, :-1]], 1), x5, torch.cat([x5[:, 1:], pad_slice], 1)], 2)
+        return _conv_bn_eval(stacked.view(B * D, 3 * C, H, W), conv, "w3cat", fold, conv.bias, 1, self.bn, True)
 
 
 def _miopen_backward(dy, x, weight, stride, mask, bias_sizes=None):
@@ -680,6 +791,28 @@ class reg2d(nn.Module):
     def _up(seq, x2d, skip=None):
         """up-convolution -> BatchNorm -> ReLU (+ ``skip``: ``conv_k + self.conv_j(x)``, models/mvs4net_utils.py:921-923)"""
         deconv, bn = seq[0], seq[1]
+        w = deconv.weight
+        if (_inference(bn, x2d) and _MFMA_CONV and deconv.stride[1:] == (2, 2) and deconv.padding[1:] == (1, 1)
+                and deconv.output_padding[1:] == (1, 1) and tuple(w.shape[2:]) == (1, 3, 3) and deconv.bias is None
+                and (skip is None or skip.is_contiguous())):
+            # inference: up-convolution, BatchNorm, ReLU and the skip connection in one kernel, weights packed once
+            N, Cin, H, W = x2d.shape
+            Cout, dev = w.shape[1], x2d.device
+            y = torch.empty(N, Cout, 2 * H, 2 * W, dtype=torch.float32, device=dev)
+            if skip is None or skip.shape == y.shape:
+                def pack():
+                    w2 = w[:, :, 0].contiguous()
+                    need = _lib.load().mvster_conv_mfma_packed_floats(Cin, Cout, 3, 2, 2)
+                    packed = torch.empty(need, dtype=torch.float32, device=dev)
+                    with _on(dev):
+                        _lib.call("mvster_conv_mfma_pack", w2.data_ptr(), packed.data_ptr(), need, Cin, Cout, 3, 2, 2, 2, _stream(dev))
+                    return packed
+                packed = _cached(deconv, "wT:mfma", (w,), pack)
+                norm = _bn_eval_norm(bn)
+                with _on(dev):
+                    _lib.call("mvster_conv_mfma_transposed_ep", x2d.data_ptr(), packed.data_ptr(), y.data_ptr(), N, Cin, Cout, H, W,
+                              2 * H, 2 * W, 3, norm.data_ptr(), skip.data_ptr() if skip is not None else None, 1, _stream(dev))
+                return y
         if deconv.stride[1:] == (2, 2) and deconv.padding[1:] == (1, 1) and deconv.output_padding[1:] == (1, 1):
             y = _conv_transpose2d_x2(x2d, deconv.weight[:, :, 0].contiguous())
         else:

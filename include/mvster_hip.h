@@ -311,10 +311,17 @@ int mvster_bn_train_bwd_nhwc(const float *dy, const float *x, const float *affin
  *   y = relu?((x - running_mean) / sqrt(running_var + eps) * gamma + beta) [+ residual],
  * ONE streaming pass instead of F.batch_norm(training=False) followed by F.relu (and the skip-connection add).
  *   scratch : 3*C floats (the per-channel affine and mean, prepared by a C-thread launch on the same stream).
- *   residual (may be NULL) as in mvster_bn_train_fwd_grouped.  _nhwc: channels-last storage, C in {4, 8, 16, 32, 64}. */
+ *   residual (may be NULL) as in mvster_bn_train_fwd_grouped.  _nhwc: channels-last storage, C in {4, 8, 16, 32, 64}.
+ *   mvster_bn_eval_prepare : only the coefficient launch -- norm[mvster_bn_eval_norm_floats(C)] = three arrays a | b | mean,
+ *       each padded with zeros to a multiple of 32 channels, a = gamma / sqrt(running_var + eps), b = beta: what the *_ep
+ *       convolution entry points take to apply the layer's BatchNorm in their epilogue (valid until the module's
+ *       parameters / buffers change). */
+long long mvster_bn_eval_norm_floats(int C);
 int mvster_bn_eval_fwd(const float *x, const float *gamma, const float *beta, const float *running_mean,
                        const float *running_var, const float *residual, float *y, float *scratch, int N, int C, int HW,
                        float eps, int relu, mvster_stream_t stream);
+int mvster_bn_eval_prepare(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                           float *norm, int C, float eps, mvster_stream_t stream);
 int mvster_bn_eval_fwd_nhwc(const float *x, const float *gamma, const float *beta, const float *running_mean,
                             const float *running_var, float *y, float *scratch, long long M, int C, float eps, int relu,
                             mvster_stream_t stream);
@@ -388,6 +395,28 @@ int mvster_conv_mfma_depth3_wgrad(const float *x, const float *dy, float *dweigh
 int mvster_conv_mfma_transposed(const float *x, const float *weight, float *y, float *workspace, long long workspace_floats,
                                 int N, int Cin, int Cout, int H, int W, int Ho, int Wo, int K, mvster_stream_t stream);
 
+/* Inference (model.eval(), no autograd -- the whole of test_mvs4.py:393-411): convolution -> BatchNorm(running statistics)
+ * -> ReLU (-> + skip connection) as ONE kernel, and the weights packed once instead of on every call.
+ * replaces: ConvBnReLU / ConvBnReLU3D / the ConvTranspose3d + BatchNorm3d + ReLU blocks and `conv_k + self.conv_j(x)` of reg2d
+ * in eval mode (models/mvs4net_utils.py:123-130,230-256,901-912,921-923).
+ *   mvster_conv_mfma_packed_floats / mvster_conv_mfma_pack : the kernels' weight layout [CinPad][K*K][CoutPad], written once per
+ *       parameter version.  op = MVSTER_CONV_OP_FWD (mode 0: weight [Cout,Cin,K,K]) or MVSTER_CONV_OP_TRANSPOSED (mode 2: weight
+ *       [Cin,Cout,K,K]); for a depth-stacked (3,k,k) layer pass its folded [Cout,3*C,k,k] weight with Cin = 3*C.
+ *   *_ep : `packed` from mvster_conv_mfma_pack (mvster_conv_direct_fwd_ep: wt as in mvster_conv_direct_fwd), no workspace;
+ *       y = relu?(fmaf(conv + bias - mean[co], a[co], b[co])) + residual   with norm = mvster_bn_eval_prepare's array
+ *       (NULL: no normalisation), residual (NULL: none) of y's shape and layout.  Bit-identical to the convolution entry
+ *       point followed by mvster_bn_eval_fwd.  depth > 0 (mvster_conv_mfma_fwd_ep): the Cin = 3*C input channels are the
+ *       depth-shifted slices of mvster_conv_mfma_depth3_fwd. */
+long long mvster_conv_mfma_packed_floats(int Cin, int Cout, int K, int stride, int op);
+int mvster_conv_mfma_pack(const float *weight, float *packed, long long packed_floats, int Cin, int Cout, int K, int stride,
+                          int op, int mode, mvster_stream_t stream);
+int mvster_conv_mfma_fwd_ep(const float *x, const float *packed, const float *bias, float *y, int N, int Cin, int Cout, int H,
+                            int W, int K, int stride, int flags, int depth, const float *norm, const float *residual, int relu,
+                            mvster_stream_t stream);
+int mvster_conv_mfma_transposed_ep(const float *x, const float *packed, float *y, int N, int Cin, int Cout, int H, int W,
+                                   int Ho, int Wo, int K, const float *norm, const float *residual, int relu,
+                                   mvster_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * F3  top-down merge of the feature pyramid, fused:  y = bilinear_x2(feat, align_corners=True) + conv1x1(skip; weight, bias).
  * replaces: models/mvs4net_utils.py:490-505 (F.interpolate + innerK 1x1 convolution + add in FPN4.forward) and, in the
@@ -419,6 +448,10 @@ int mvster_conv_direct_fwd(const float *x, const float *wt, const float *bias, f
                            int W, int K, mvster_stream_t stream);
 int mvster_conv_direct_fwd_layout(const float *x, const float *wt, const float *bias, float *y, int N, int CIN, int COUT,
                                   int H, int W, int K, int out_layout, mvster_stream_t stream);
+/* Inference: the layer's eval-mode BatchNorm + ReLU (+ skip connection) in the convolution's epilogue, see F2/F3 below. */
+int mvster_conv_direct_fwd_ep(const float *x, const float *wt, const float *bias, float *y, int N, int CIN, int COUT, int H,
+                              int W, int K, int out_layout, const float *norm, const float *residual, int relu,
+                              mvster_stream_t stream);
 long long mvster_conv_direct_wgrad_workspace(int N, int CIN, int COUT, int H, int W, int K);
 int mvster_conv_direct_wgrad(const float *x, const float *dy, float *dweight, float *dbias, float *workspace,
                              long long workspace_floats, int N, int CIN, int COUT, int H, int W, int K,
