@@ -93,6 +93,15 @@ struct FwdTile {
     static constexpr int PS = S == 1 ? round_to_residue(PLANE, 64, 32) : (PLANE | 1);
     static constexpr int COW = NB * 32;
     static constexpr int WPS = round_to_residue(KK * COW, 64, 32);
+    // Two LDS buffers (the next chunk is written while this one feeds the matrix cores, one barrier per chunk) where two
+    // workgroups still fit a CU with them.  Measured without (tools/probes/variant.sh, MVSTER_PROBE_MF_*): kernel time =
+    // MFMA time (at 99 % of the pipe's rate) + the time of everything else -- the co-resident workgroups run in lockstep,
+    // so nothing fills the pipe while a workgroup stages.
+#ifndef MVSTER_MF_DOUBLE_BUFFER
+#define MVSTER_MF_DOUBLE_BUFFER 1
+#endif
+    static constexpr bool DB = MVSTER_MF_DOUBLE_BUFFER && 2 * CB * (PS + WPS) * 4 <= 80 * 1024;
+    static constexpr int NBUF = DB ? 2 : 1;
 };
 
 template <int KS, int S, int NB, int CB, bool EP>
@@ -109,8 +118,9 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
     constexpr int ROW4 = COW / 4, W4 = CB * KK * ROW4;             // packed weights of a chunk as float4s
     constexpr int NW = (W4 + kBlock - 1) / kBlock;
     static_assert(CB % 4 == 0, "planes are dealt to the four waves");
-    __shared__ float il[CB * PS];
-    __shared__ __attribute__((aligned(16))) float wl[CB * WPS];
+    constexpr bool DB = T::DB;
+    __shared__ float il_all[T::NBUF * CB * PS];
+    __shared__ __attribute__((aligned(16))) float wl_all[T::NBUF * CB * WPS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, p = lane & 31;
     int t = blockIdx.x;
     const int tx = t % d.tiles_x;
@@ -155,7 +165,9 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
                            : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     };
-    auto stage = [&]() {                                           // registers -> LDS
+    auto stage = [&](int buf) {                                    // registers -> LDS
+        float* __restrict__ il = il_all + buf * (CB * PS);
+        float* __restrict__ wl = wl_all + buf * (CB * WPS);
 #pragma unroll
         for (int pp = 0; pp < PPW; ++pp)
 #pragma unroll
@@ -171,17 +183,38 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
         }
     };
 
+    // One iteration = one chunk of CB input channels.  Double-buffered: chunk k feeds the matrix cores from buffer k & 1
+    // while chunk k+1 (fetched during chunk k-1) is written to the other buffer after the first MFMAs have been issued,
+    // and chunk k+2 leaves for the registers -- one barrier per chunk, the pipe never waits for a staging phase.
+    constexpr int UNITS = KK * (CB / 2);                           // (tap, channel pair) steps of a chunk
+    constexpr int SPLIT = UNITS >= 8 ? 4 : UNITS / 2;              // the next chunk is staged after this many of them
     fetch(0);
-    for (int ci0 = 0; ci0 < d.CinPad; ci0 += CB) {
-        if (ci0 > 0) __syncthreads();                              // the previous chunk has been consumed
-        stage();
+    if constexpr (DB) {
+        stage(0);
         __syncthreads();
-        if (ci0 + CB < d.CinPad) fetch(ci0 + CB);
+        if (CB < d.CinPad) fetch(CB);
+    }
+    int buf = 0;
+    for (int ci0 = 0; ci0 < d.CinPad; ci0 += CB) {
+        if constexpr (!DB) {
+            if (ci0 > 0) __syncthreads();                          // the previous chunk has been consumed
+            stage(0);
+            __syncthreads();
+            if (ci0 + CB < d.CinPad) fetch(ci0 + CB);
+        }
+        const float* __restrict__ il = il_all + buf * (CB * PS);
+        const float* __restrict__ wl = wl_all + buf * (CB * WPS);
 #pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
+        for (int u = 0; u < UNITS; ++u) {
+            const int tap = u / (CB / 2), c = 2 * (u % (CB / 2));
             const int ky = tap / KS, kx = tap - ky * KS;
-#pragma unroll
-            for (int c = 0; c < CB; c += 2) {
+            if constexpr (DB) {
+                if (u == SPLIT && ci0 + CB < d.CinPad) {
+                    stage(buf ^ 1);
+                    if (ci0 + 2 * CB < d.CinPad) fetch(ci0 + 2 * CB);
+                }
+            }
+            {
                 float a[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) a[nb] = wl[(c + h) * WPS + tap * COW + nb * 32 + p];
@@ -189,9 +222,21 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
                 for (int r = 0; r < 2; ++r) {
                     const float b = il[(c + h) * PS + ((2 * wave + r) * S + ky) * IN_W + p * S + kx];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], b, acc[r][nb], 0, 0, 0);
+                    for (int nb = 0; nb < NB; ++nb) {
+#if defined(MVSTER_PROBE_MF_NO_MFMA)         // timing probes (tools/probes/variant.sh); results are wrong when defined
+                        acc[r][nb][0] += a[nb] * b;
+#elif defined(MVSTER_PROBE_MF_NO_LDS_READS)
+                        acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)tap, (float)c, acc[r][nb], 0, 0, 0);
+#else
+                        acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], b, acc[r][nb], 0, 0, 0);
+#endif
+                    }
                 }
             }
+        }
+        if constexpr (DB) {
+            __syncthreads();                                       // buffer `buf` is free, the other one is complete
+            buf ^= 1;
         }
     }
     // D: column (pixel) = lane & 31, row (output channel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): registers
@@ -960,6 +1005,28 @@ extern "C" long long mvster_conv_mfma_workspace(int N, int Cin, int Cout, int H,
     } while (0)
 
 namespace mvster {
+// 64 or 32 output channels per workgroup?  The kernels are bound by the matrix pipe, and a launch is a few "rounds" of
+// resident workgroups: what counts is how many MFMA-carrying waves a SIMD has to work through, round by round.  With 64
+// channels a workgroup stages its input tile once for twice the work (2 workgroups fit a CU); with 32 there are twice as
+// many workgroups of half the length (3 fit): better whenever the grid does not fill the chip several times over -- the
+// low-resolution layers of reg2d / FPN4 (tools/probes/conv_calls.py: 64 -> 64 at 18 x 25 pixels is 24 workgroups of 92 us).
+#ifndef MVSTER_MF_PICK_BLOCKS
+#define MVSTER_MF_PICK_BLOCKS 1
+#endif
+static bool two_blocks_pay(long long tiles, int CoutPad) {
+    if (CoutPad % 64 != 0) return false;
+    if (!MVSTER_MF_PICK_BLOCKS) return true;
+    auto simd_work = [](long long wgs, int per_cu, double work) {       // sum over rounds of (waves per SIMD x work per wave)
+        const long long slots = 256LL * per_cu, full = wgs / slots, rest = wgs % slots;
+        return work * ((double)full * per_cu + (double)((rest + 255) / 256));
+    };
+    const long long wg2 = tiles * (CoutPad / 64), wg1 = tiles * (CoutPad / 32);
+    // (1.3: with 32 channels per workgroup the input tile is staged twice and every MFMA needs 1.5 instead of 1 LDS reads --
+    // measured, a 32-channel workgroup takes 0.65 of a 64-channel one, not 0.5: 64 -> 64 at 18 x 25 and 36 x 50 pixels
+    // 133 -> 87 us, while the 630-tile layers (64 -> 64 at 144 x 200 x 5 views) gain nothing and stay on 64)
+    return simd_work(wg2, 2, 2.0) <= 1.3 * simd_work(wg1, 3, 1.0);
+}
+
 struct EpilogueArgs {         // host side of ConvEpilogue
     const float* norm;
     const float* residual;
@@ -1004,7 +1071,7 @@ static int conv_mfma_fwd_impl(const float* x, const float* weight, const float* 
     if (!prepacked)
         hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
                            K * K, d.CinPad, d.CoutPad, pack_mode);
-    const bool two = d.CoutPad % 64 == 0;                          // 64 output channels per workgroup when they divide
+    const bool two = two_blocks_pay(tiles, d.CoutPad);             // 64 output channels per workgroup, or 32
     if (K == 1 && d.CoutPad == 96) {                               // 1x1, 65-96 output channels (FPN4's head contraction 64 -> 72):
         const dim3 grid((unsigned)tiles, 1);                       // all three blocks from one pass over the input tile
         MVSTER_MFMA_FWD(1, 1, 3, MVSTER_MF_CB_S1);
@@ -1073,7 +1140,7 @@ static int conv_mfma_transposed_impl(const float* x, const float* weight, float*
     if (!prepacked)
         hipLaunchKernelGGL(conv_mfma_pack_kernel, dim3(grid_for(packed, kBlock)), dim3(kBlock), 0, st, weight, workspace, Cin, Cout,
                            K * K, d.CinPad, d.CoutPad, 2);
-    const bool two = d.CoutPad % 64 == 0;
+    const bool two = two_blocks_pay(tiles, d.CoutPad);
     const dim3 grid((unsigned)tiles, d.CoutPad / (two ? 64 : 32));
     if (K == 3) { if (two) MVSTER_MFMA_TR(3, 2, 8); else MVSTER_MFMA_TR(3, 1, 8); }
     else { if (two) MVSTER_MFMA_TR(5, 2, 4); else MVSTER_MFMA_TR(5, 1, 4); }

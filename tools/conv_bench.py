@@ -16,6 +16,7 @@ from deep_reconstruction_with_epipolar_lines_mvster_amd import mvs4net      # no
 ap = argparse.ArgumentParser()
 ap.add_argument("--views", type=int, default=5)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--only", default="", help="substring of the layer names to run")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 H, W, V = 1152, 1600, args.views
@@ -51,6 +52,8 @@ def timed(fn):
 tot = [0.0, 0.0, 0.0]
 print("%-28s %7s | %-22s | %-22s | %-22s" % ("layer", "GFLOP", "forward", "input gradient", "weight gradient"))
 for name, N, ci, co, k, s, h, w in LAYERS:
+    if args.only and not any(o in name for o in args.only.split(",")):
+        continue
     x = torch.randn(N, ci, h, w, device=dev)
     if s == 0:
         wt = torch.randn(ci, co, k, k, device=dev)
