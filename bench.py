@@ -187,13 +187,18 @@ def kernel_symbol(entry, B, C, G, D, H, W, S):
     return entry.replace("mvster_", "") + "_kernel"
 
 
+HOT_PATH_SOURCES = ("cost_volume_*.hip", "cost_volume_common.h", "mvster_device.h", "mvster_host.h", "layout.hip", "pose.hip",
+                    "ranges.hip", "regress.hip", "warp.hip")
+
+
 def source_fingerprint():
-    """sha256 over the kernel sources and the ABI header: ties a committed PMC summary to the code it was taken from."""
+    """sha256 over the sources of the hot-path kernels (everything a bench.py step launches): ties a committed PMC summary
+    to the code it was taken from.  The F2/F3 translation units (convolutions, BatchNorm, FPN merge, Sinkhorn) and the ABI
+    header's declarations are not part of it: they do not change what the summarised kernels do."""
     import glob
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "deep_reconstruction_with_epipolar_lines_mvster_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + \
-            [os.path.join(ROOT, "include", "mvster_hip.h")]:
+    for f in sorted(f for pat in HOT_PATH_SOURCES for f in glob.glob(os.path.join(csrc, pat))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -652,6 +657,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="reference views per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scene", action="store_true", help="skip the informational run of the same step on scene features")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end MVS4net step timed after the headline region")
     ap.add_argument("--data", default="noise", choices=["noise", "scene"],
                     help="noise: N(0,1) features (SURVEY 8d; spatially random depth, worst case for gather/scatter); "
@@ -787,6 +793,21 @@ def main():
                 "measured_ceiling_TBps": "10.5-16.2 (profiles/r3_gather_probe.txt: the same 128 B per sample gathered with no arithmetic, "
                                          "by address pattern)",
                 "note": "informational: roofline above prices the dominant entry against HBM as the contract asks"}
+        if world == 1 and not args.no_scene and other is None and args.data == "noise" and B == 4:
+            # the same step on multi-view-consistent features (smooth depth, like real scenes: the hypotheses of neighbouring
+            # pixels land next to each other in the source views); after and outside the timed region, informational
+            stages.clear()
+            torch.cuda.empty_cache()
+            try:
+                stages2, dv2 = make_inputs(B, seed=rank_seed(rank), device=device, data="scene")
+                step2 = lambda: hot_path_step(stages2, dv2, net, device)          # noqa: E731
+                el2 = timed_region(step2, 10, 3, device, 1)
+                out["scene_data"] = {"value": round(B * 10 / el2, 1), "unit": "ref-views/s", "ms_per_step": round(1e3 * el2 / 10, 3),
+                                     "steps": 10, "warmup": 3,
+                                     "note": "same workload and code on synthetic multi-view-consistent scene features (--data scene)"}
+                stages2.clear()
+            except Exception as exc:                               # noqa: BLE001 -- the headline line must survive
+                out["scene_data"] = {"error": str(exc)[:300]}
         if world == 1 and not args.no_e2e and other is None:
             # after and outside the timed region; frees the hot-path inputs first
             stages.clear()
