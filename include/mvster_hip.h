@@ -116,10 +116,13 @@ int mvster_cost_volume_fwd(const float *ref, const float *const *srcs, int S, co
 
 /* A2 in training mode: the same forward, which additionally takes the FIRST pass of the binned backward's counting sort
  * while it has every sample's projection at hand: bin_counts[mvster_cost_volume_bin_counts(...)] (int32, zeroed by the
- * call) receives, per (batch, view, tile of the source map), the number of (pixel, hypothesis) samples whose 2x2
- * footprint touches the tile.  Hand it to mvster_cost_volume_bwd_ws as fwd_bin_counts.  bin_counts == NULL: plain
- * mvster_cost_volume_fwd.  Channels-last only (MVSTER_ERR_UNSUPPORTED otherwise).
- *   mvster_cost_volume_bin_counts : number of int32 counters for this shape, 0 when the binned route does not exist.
+ * call) receives, per (batch, view, tile of the source map, category), the number of (pixel, hypothesis) samples whose
+ * upper-left tap lies in the tile; category = interior / bottom row / right column / corner of the tile, i.e. which
+ * neighbouring tiles the sample's 2x2 footprint also reaches (every sample is counted exactly once).  Hand it to
+ * mvster_cost_volume_bwd_ws as fwd_bin_counts.  bin_counts == NULL: plain mvster_cost_volume_fwd.  Channels-last only
+ * (MVSTER_ERR_UNSUPPORTED otherwise).
+ *   mvster_cost_volume_bin_counts : number of int32 counters for this shape (B * S * tiles * 4), 0 when the binned route
+ *       does not exist.
  */
 long long mvster_cost_volume_bin_counts(int S, int B, int C, int G, int D, int H, int W, int Hs, int Ws, int layout);
 int mvster_cost_volume_fwd_counted(const float *ref, const float *const *srcs, int S, const float *pose,
@@ -160,7 +163,8 @@ int mvster_cost_volume_bwd(const float *gvol, const float *vol, const float *wsu
  * (pixel, hypothesis) samples by destination tile of the source map, and one workgroup per tile that sorts its samples
  * by source pixel in LDS, sums them in registers (one owner lane per pixel) and writes the tile once with plain stores.
  * The workspace holds the
- * coefficients [B,S,H*W,D,G] and the sort's arrays (worst case 4 tile entries per sample): see DESIGN.md section 3.
+ * coefficients [B,S,H*W,D,G] and the sort's arrays (counters, scan partials, offsets, cursors: one int32 per bin each, and
+ * ONE 4-byte item per (sample, view): B*S*H*W*D words): see DESIGN.md section 3.
  * A workspace of only B*S*H*W*D*G words selects the round-1 TILE_SCATTER route for D = 8, C >= 16;
  * workspace == NULL or anything shorter: identical to mvster_cost_volume_bwd.  The library never allocates.
  * fwd_bin_counts: the counters mvster_cost_volume_fwd_counted filled for the same inputs, or NULL.  With them the binned
@@ -184,7 +188,7 @@ int mvster_cost_volume_bwd_ws(const float *gvol, const float *vol, const float *
 /* Which kernel family mvster_cost_volume_bwd_ws runs for a shape and workspace size (so that tests and the
  * benchmark can state -- and assert -- the route instead of mirroring the dispatch rules).
  * mvster_cost_volume_bwd_route_name: the route's kernels as rocprofv3 prints them, dominant first, ';'-separated, e.g.
- * "tile_owner_c8_kernel<4, 4>;cost_volume_bwd_nhwc_kernel<8, 4, 4, 1, true>"; writes at most `cap` bytes including the
+ * "tile_owner_c8_kernel<4, 4>;cost_volume_bwd_coef_kernel<8, 4, 4>"; writes at most `cap` bytes including the
  * terminator and returns the length it wanted to write (0 for MVSTER_BWD_ROUTE_NONE). */
 #define MVSTER_BWD_ROUTE_NONE 0          /* shape not instantiated: the entry point returns MVSTER_ERR_UNSUPPORTED   */
 #define MVSTER_BWD_ROUTE_PLANAR 1        /* NCHW planes, tap-by-tap atomics                                           */
