@@ -534,9 +534,15 @@ def conv_flops(name, a):
     if name == "mvster_conv_mfma_transposed":
         N, Cin, Cout, H, W = a[5:10]
         return 2.0 * N * Cin * Cout * a[12] * a[12] * H * W
-    if name == "mvster_conv_direct_fwd":
+    if name in ("mvster_conv_direct_fwd", "mvster_conv_direct_fwd_layout", "mvster_conv_direct_fwd_ep"):
         N, Cin, Cout, H, W, K = a[4:10]
         return 2.0 * N * Cin * Cout * K * K * H * W
+    if name == "mvster_conv_mfma_fwd_ep":          # (x, packed, bias, y, N, Cin, Cout, H, W, K, stride, ...): Cin counts the virtual channels
+        N, Cin, Cout, H, W, K, st = a[4:11]
+        return 2.0 * N * Cin * Cout * K * K * (H // st) * (W // st)
+    if name == "mvster_conv_mfma_transposed_ep":   # (x, packed, y, N, Cin, Cout, H, W, Ho, Wo, K, ...)
+        N, Cin, Cout, H, W = a[3:8]
+        return 2.0 * N * Cin * Cout * a[10] * a[10] * H * W
     if name == "mvster_conv_direct_wgrad":
         N, Cin, Cout, H, W, K = a[6:12]
         return 2.0 * N * Cin * Cout * K * K * H * W

@@ -147,3 +147,21 @@ def test_pmc_traffic_goes_null_when_the_kernel_sources_changed(tmp_path):
     f.write_text(json.dumps(doc))
     assert bench.pmc_traffic("some_kernel<1>", path=str(f))[0] is None
     assert bench.pmc_traffic("other_kernel", path=str(f))[0] is None
+
+
+def test_conv_flops_know_every_convolution_entry_point():
+    """The e2e object's convolution TFLOP/s counts the inference entry points (weights pre-packed, BatchNorm in the epilogue)
+    like the training ones: same layer, same flops."""
+    import bench
+    N, Cin, Cout, H, W, K = 5, 32, 64, 288, 400, 3
+    want = 2.0 * N * Cin * Cout * K * K * H * W
+    p = 0                                                      # pointers are opaque to the formula
+    assert bench.conv_flops("mvster_conv_mfma_fwd", (p, p, p, p, p, 0, N, Cin, Cout, H, W, K, 1, 0, p)) == want
+    assert bench.conv_flops("mvster_conv_mfma_fwd_ep", (p, p, p, p, N, Cin, Cout, H, W, K, 1, 0, 0, p, p, 1, p)) == want
+    assert bench.conv_flops("mvster_conv_direct_fwd", (p, p, p, p, N, Cin, Cout, H, W, K, p)) == want
+    assert bench.conv_flops("mvster_conv_direct_fwd_ep", (p, p, p, p, N, Cin, Cout, H, W, K, 0, p, p, 1, p)) == want
+    assert bench.conv_flops("mvster_conv_direct_fwd_layout", (p, p, p, p, N, Cin, Cout, H, W, K, 1, p)) == want
+    tr = 2.0 * N * Cin * Cout * K * K * H * W                  # transposed: per INPUT pixel
+    assert bench.conv_flops("mvster_conv_mfma_transposed", (p, p, p, p, 0, N, Cin, Cout, H, W, 2 * H, 2 * W, K, p)) == tr
+    assert bench.conv_flops("mvster_conv_mfma_transposed_ep", (p, p, p, N, Cin, Cout, H, W, 2 * H, 2 * W, K, p, p, 1, p)) == tr
+    assert bench.conv_flops("mvster_bn_eval_prepare", (p,) * 8) == 0.0
