@@ -200,9 +200,27 @@ tile_owner_kernel(OwnerArgs a) {
     constexpr int TW = T::TW, TH = T::TH, BW = T::BW, NCELL = T::NCELL, NT = T::NT, KPT = T::KPT, CHUNK = T::CHUNK;
     constexpr int LW = BinTile<C>::kLw, LH = BinTile<C>::kLh;
     constexpr int CPG = C / G;
-    constexpr int CH = 8;                                          // channels per walk: 4 taps x 8 accumulators per lane
+    // Channels per walk and samples in flight per owner, swept in round 3 (tools/probes/ab_owner.sh; us per launch at DTU
+    // stages 3 / 2 / 1, B = 4, noise):   CH 8, PF 2 (round 2)  975 / 790 / 309      CH 8, PF 1  982 / 793 / 349      CH 8, PF 4  1468 / 924 / 313
+    //                                    CH 16, PF 1           920 / 704 / 283      CH 16, PF 2  1324 / 788 / 267
+    // A walk step is one dependent round trip to L2 / HBM whatever it fetches, so 16 channels per step halve the steps of the
+    // 16-channel stage (one pass over the lists instead of two) -- as long as the registers still allow three waves per SIMD.
+    // What the walk really loses is balance: with every owner walking the MEAN list length it takes 626 / 441 us (the longest
+    // list of a wave is about twice the mean on noise).  Tried against that and dropped: lists capped at ~1.25 x mean with the
+    // excess dealt to all lanes and everything accumulated by LDS double-precision atomics (ds_add_f64; the tile image
+    // channel-major so that an instruction's lanes fall on different banks): 923 / 812 / 286 -- the excess pass is its own
+    // dependent chain (binary search, record, gathers, atomics) in front of every wave's walk, and tighter caps made it worse
+    // (mean + 1: 1077 / 1004 / 294); the C = 8 kernel's LDS-staged records at C = 16 (80-byte records, 192 or 384 per chunk):
+    // 931 / 1199 us against 924 -- three waves per SIMD at best, and twice the LDS traffic per sample.
+#ifndef MVSTER_OWNER_CH
+#define MVSTER_OWNER_CH 16
+#endif
+    constexpr int CH = MVSTER_OWNER_CH < C ? MVSTER_OWNER_CH : C;  // channels per walk: 4 taps x CH accumulators per lane
     constexpr int GPC = CH / CPG > 0 ? CH / CPG : 1;               // coefficient groups a channel chunk spans
-    constexpr int PF = 2;                                          // samples in flight per owner
+#ifndef MVSTER_OWNER_PF
+#define MVSTER_OWNER_PF (C == 64 ? 2 : 1)
+#endif
+    constexpr int PF = MVSTER_OWNER_PF;                            // samples in flight per owner
     static_assert(CPG <= CH ? CH % CPG == 0 : CPG % CH == 0, "a channel chunk holds whole groups or lies inside one");
     __shared__ SampleRec sorted[CHUNK];
     __shared__ int cnt[NT], start[NT];
@@ -288,9 +306,11 @@ tile_owner_kernel(OwnerArgs a) {
             if (cell[j] >= 0) sorted[start[cell[j]] + slot[j]] = rec[j];
         lds_barrier();
 
-        // ---- every owner walks its samples, eight channels at a time ---------------------------------------------------
-#ifdef MVSTER_PROBE_OWNER_NO_WALK            // timing probe (tools/probes/ab_owner.sh); results are wrong when defined
+        // ---- every owner walks its samples, CH channels at a time ---------------------------------------------------
+#ifdef MVSTER_PROBE_OWNER_NO_WALK            // timing probes (tools/probes/ab_owner.sh); results are wrong when defined
         const int mine = 0, first = 0;
+#elif defined(MVSTER_PROBE_OWNER_EVEN_WALK)
+        const int mine = owner ? (m + NCELL - 1) / NCELL : 0, first = 0;        // every owner walks the mean count
 #else
         const int mine = owner ? cnt[tid] : 0, first = owner ? start[tid] : 0;
 #endif
@@ -304,7 +324,7 @@ tile_owner_kernel(OwnerArgs a) {
             // the latency of these gathers (coefficients and reference features come from HBM / L2), not by arithmetic.
             for (int k = 0; k < mine; k += PF) {
                 SampleRec r[PF];
-                float4 r0[PF], r1[PF];
+                float4 rq[PF][CH / 4];
                 float cf[PF][GPC];
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
@@ -315,8 +335,8 @@ tile_owner_kernel(OwnerArgs a) {
                 for (int u = 0; u < PF; ++u) {
                     const int pj = r[u].id / D;
                     const float4* __restrict__ rp = reinterpret_cast<const float4*>(ref + (size_t)pj * C + ch);
-                    r0[u] = rp[0];
-                    r1[u] = rp[1];
+#pragma unroll
+                    for (int i = 0; i < CH / 4; ++i) rq[u][i] = rp[i];
                     const float* __restrict__ cp = dcor + (size_t)r[u].id * G + ch / CPG;
                     if constexpr (GPC == 8) {
                         const float4 a0 = reinterpret_cast<const float4*>(cp)[0], a1 = reinterpret_cast<const float4*>(cp)[1];
@@ -334,7 +354,11 @@ tile_owner_kernel(OwnerArgs a) {
                 }
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
-                    const float rv[CH] = {r0[u].x, r0[u].y, r0[u].z, r0[u].w, r1[u].x, r1[u].y, r1[u].z, r1[u].w};
+                    float rv[CH];
+#pragma unroll
+                    for (int i = 0; i < CH / 4; ++i) {
+                        rv[4 * i] = rq[u][i].x; rv[4 * i + 1] = rq[u][i].y; rv[4 * i + 2] = rq[u][i].z; rv[4 * i + 3] = rq[u][i].w;
+                    }
                     float w[4];
                     weights_from_fraction(r[u].fx, r[u].fy, r[u].mask, w);
 #pragma unroll
@@ -351,11 +375,12 @@ tile_owner_kernel(OwnerArgs a) {
                 const int lx = cbx - 1 + (kk & 1), ly = cby - 1 + (kk >> 1);
                 if (owner && (unsigned)lx < (unsigned)TW && (unsigned)ly < (unsigned)TH) {
                     float4* __restrict__ o = reinterpret_cast<float4*>(&out[(ly * TW + lx) * C + ch]);
-                    float4 u = o[0], v = o[1];
-                    u.x += acc[kk][0]; u.y += acc[kk][1]; u.z += acc[kk][2]; u.w += acc[kk][3];
-                    v.x += acc[kk][4]; v.y += acc[kk][5]; v.z += acc[kk][6]; v.w += acc[kk][7];
-                    o[0] = u;
-                    o[1] = v;
+#pragma unroll
+                    for (int i = 0; i < CH / 4; ++i) {
+                        float4 u = o[i];
+                        u.x += acc[kk][4 * i]; u.y += acc[kk][4 * i + 1]; u.z += acc[kk][4 * i + 2]; u.w += acc[kk][4 * i + 3];
+                        o[i] = u;
+                    }
                 }
                 lds_barrier();
             }
